@@ -1,0 +1,70 @@
+// Shared device helpers for the lc2is_amd gfx950 (CDNA4 / MI355X) kernels.
+// Everything here is written for wave64 + MFMA + LDS; there is no other target.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short bf16_t;  // raw bf16 bits in HBM
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+typedef __attribute__((ext_vector_type(2))) int i32x2_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+
+#define LC2IS_OK 0
+#define LC2IS_ERR_SHAPE (-1)
+#define LC2IS_ERR_NULL (-2)
+#define LC2IS_ERR_UNSUPPORTED (-3)
+#define LC2IS_ERR_WORKSPACE (-4)
+#define LC2IS_ERR_LAUNCH (-5)
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) {
+  return __builtin_bit_cast(float, ((unsigned)v) << 16);
+}
+
+// round-to-nearest-even; NaN stays NaN (plain cast lowers to v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, b);
+}
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+}
+
+// 128-bit buffer resource over [base, base+bytes): out-of-range loads return 0,
+// out-of-range stores are dropped (hardware range check) — used for every tile edge.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Bijective XCD-aware remap of a 1-D block id: blocks b and b+8 share an XCD
+// (round-robin dispatch), so give every XCD one contiguous chunk of the tile list
+// and neighbouring tiles (which share operand panels) hit the same L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int xcd = bid & 7;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}
+
+static inline int lc2is_check_launch() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? LC2IS_OK : LC2IS_ERR_LAUNCH;
+}

@@ -1,0 +1,308 @@
+// dW[N,K] (fp32) = dY[M,N]^T · X[M,K]  — the weight gradient of every nn.Linear on the hot path
+// (autograd of the calls listed in gemm_nt.hip; reference engine.py:100 loss.backward()).
+//
+// The reduction runs over M (tokens), the slow dimension of BOTH operands, so neither tile can be
+// read as a k-contiguous MFMA fragment.  gfx950 answers that with ds_read_b64_tr_b16: tiles are staged
+// row-major [64 tokens][128 columns] (coalesced 16-byte global loads, range-checked so the token tail
+// reads as zero) into LDS with the 256-byte-row XOR swizzle  chunk ^= ((row&3)<<2)|((row>>2)&3),
+// and each 16x16x32 bf16 MFMA fragment is two transposed reads (4 token rows x 16 columns per 16-lane
+// group), conflict-free under that swizzle.  MFMA A = X^T (rows = k), B = dY (cols = n), so a lane's 4
+// accumulator registers are 4 consecutive k of one n: 16-byte fp32 stores into dW[n][k..k+3].
+// Occupancy: the output is only (N/128)x(K/128) tiles, so M is cut into `splits` ranges; each writes an
+// fp32 slab and a second launch sums the slabs in a fixed order (bitwise reproducible, no atomics).
+#include "common.h"
+#include "lc2is_hip.h"
+
+namespace {
+
+constexpr int TN_BN = 128, TN_BK = 128, TN_BM = 64;
+constexpr int TN_TILE_BYTES = TN_BM * 256;  // one operand tile: 64 rows x 256 B
+constexpr int TN_STAGE = 2 * TN_TILE_BYTES;
+
+struct TnPlan {
+  int ntn, ntk, splits, chunk;
+};
+
+inline TnPlan tn_plan(int M, int N, int K) {
+  TnPlan p;
+  p.ntn = (N + TN_BN - 1) / TN_BN;
+  p.ntk = (K + TN_BK - 1) / TN_BK;
+  const int tiles = p.ntn * p.ntk;
+  int splits = 1024 / tiles;
+  const int max_splits = (M + 511) / 512;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  int chunk = (M + splits - 1) / splits;
+  chunk = (chunk + TN_BM - 1) / TN_BM * TN_BM;
+  p.splits = (M + chunk - 1) / chunk;
+  p.chunk = chunk;
+  return p;
+}
+
+__device__ __forceinline__ int tn_swz(int row, int ch) {
+  return row * 256 + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
+}
+
+__device__ __forceinline__ bf16x8_t tr_frag(const char* tile, int addr_lo, int addr_hi) {
+  // two transposed 4x16 block reads -> the 8 reduction-dim elements of one 16x16x32 fragment
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4_t*)LDS_PTR(tile + addr_lo));
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4_t*)LDS_PTR(tile + addr_hi));
+  s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__ dY, int ldy,
+                                                       const bf16_t* __restrict__ X, int ldx, float* out,
+                                                       int ldo, size_t split_stride, int M, int N, int K,
+                                                       int ntn, int ntk, int chunk, int accumulate) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wk = wid >> 1, wn = wid & 1;
+  const int tiles = ntn * ntk;
+  const int split = blockIdx.x / tiles;
+  const int tile = blockIdx.x % tiles;
+  const int n0 = (tile / ntk) * TN_BN, k0 = (tile % ntk) * TN_BK;
+  const int m_begin = split * chunk;
+  int m_end = m_begin + chunk;
+  if (m_end > M) m_end = M;
+  const int nsteps = (m_end - m_begin + TN_BM - 1) / TN_BM;
+
+  // rows >= m_end must read as zero: the descriptor ends at row m_end (the next split owns the rest)
+  const __amdgpu_buffer_rsrc_t rsY = make_rsrc(dY, (unsigned)m_end * (unsigned)ldy * 2u);
+  const __amdgpu_buffer_rsrc_t rsX = make_rsrc(X, (unsigned)m_end * (unsigned)ldx * 2u);
+
+  // staging: thread handles 4 chunks per operand: chunk c -> row c>>4, 16-byte column chunk c&15
+  int y_goff[4], x_goff[4], st_lds[4];
+  bool y_ok[4], x_ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + i * 256, row = c >> 4, ch = c & 15;
+    y_ok[i] = (n0 + ch * 8) < N;
+    x_ok[i] = (k0 + ch * 8) < K;
+    y_goff[i] = ((m_begin + row) * ldy + n0 + ch * 8) * 2;
+    x_goff[i] = ((m_begin + row) * ldx + k0 + ch * 8) * 2;
+    st_lds[i] = tn_swz(row, ch);
+  }
+
+  // transposed-read addresses (bytes inside a tile), per 32-row sub-step s and sub-tile t:
+  // group g = lane>>4 owns reduction rows 8g..8g+7; lane 4q+p of the group addresses row 8g+q (+4),
+  // columns 16*t' + 4p .. +3  ->  chunk = 2*t' + (p>>1), byte 8*(p&1) inside the chunk.
+  const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+  int xa_lo[2][4], xa_hi[2][4], ya_lo[2][4], ya_hi[2][4];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int r_lo = 32 * s + 8 * g + q, r_hi = r_lo + 4;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int chx = (wk * 64 + t * 16) / 8 + (pp >> 1);
+      const int chy = (wn * 64 + t * 16) / 8 + (pp >> 1);
+      xa_lo[s][t] = tn_swz(r_lo, chx) + 8 * (pp & 1);
+      xa_hi[s][t] = tn_swz(r_hi, chx) + 8 * (pp & 1);
+      ya_lo[s][t] = tn_swz(r_lo, chy) + 8 * (pp & 1);
+      ya_hi[s][t] = tn_swz(r_hi, chy) + 8 * (pp & 1);
+    }
+  }
+
+  f32x4_t acc[4][4];  // [k sub-tile][n sub-tile]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  i32x4_t ry[4], rx[4];
+  auto gload = [&](int step) {
+    const int yb = step * TN_BM * ldy * 2, xb = step * TN_BM * ldx * 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ry[i] = __builtin_amdgcn_raw_buffer_load_b128(rsY, y_ok[i] ? y_goff[i] + yb : -1, 0, 0);
+      rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, x_ok[i] ? x_goff[i] + xb : -1, 0, 0);
+    }
+  };
+  auto lstore = [&](char* stage) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *(i32x4_t*)(stage + st_lds[i]) = ry[i];
+      *(i32x4_t*)(stage + TN_TILE_BYTES + st_lds[i]) = rx[i];
+    }
+  };
+
+  if (nsteps > 0) {
+    gload(0);
+    lstore(smem);
+  }
+  __syncthreads();
+
+  for (int st = 0; st < nsteps; ++st) {
+    const char* cur = smem + (st & 1) * TN_STAGE;
+    char* nxt = smem + ((st + 1) & 1) * TN_STAGE;
+    const bool more = (st + 1) < nsteps;
+    if (more) gload(st + 1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8_t xf[4], yf[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        yf[t] = tr_frag(cur, ya_lo[s][t], ya_hi[s][t]);
+        xf[t] = tr_frag(cur + TN_TILE_BYTES, xa_lo[s][t], xa_hi[s][t]);
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[a], yf[b], acc[a][b], 0, 0, 0);
+    }
+    if (more) lstore(nxt);
+    __syncthreads();
+  }
+
+  float* o = out + (size_t)split * split_stride;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int n = n0 + wn * 64 + b * 16 + (lane & 15);
+    if (n >= N) continue;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int k = k0 + wk * 64 + a * 16 + g * 4;
+      if (k >= K) continue;
+      float* dst = o + (size_t)n * ldo + k;
+      f32x4_t v = acc[a][b];
+      if (accumulate) v += *(const f32x4_t*)dst;
+      *(f32x4_t*)dst = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ ws, int splits,
+                                                           size_t split_stride, float* out, int ldo, int N,
+                                                           int K, int accumulate) {
+  const int K4 = K >> 2;
+  const size_t total = (size_t)N * K4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int n = (int)(i / K4), k4 = (int)(i % K4);
+    const float4* src = reinterpret_cast<const float4*>(ws + (size_t)n * K) + k4;
+    float4 s = *src;
+    for (int sp = 1; sp < splits; ++sp) {
+      const float4 v = *reinterpret_cast<const float4*>(ws + sp * split_stride + (size_t)n * K + 4 * k4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    float4* dst = reinterpret_cast<float4*>(out + (size_t)n * ldo) + k4;
+    if (accumulate) {
+      const float4 d = *dst;
+      s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
+    }
+    *dst = s;
+  }
+}
+
+// ---- bias gradient: column sums of a bf16 [M,N] matrix -------------------------------------------------
+constexpr int CS_ROWBLOCKS = 128;
+
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ dY, int ldy, float* ws, int M,
+                                                      int N) {
+  // block (bx, by): 64 column groups of 8 (lane) x 4 row lanes (wave); rows by*4+wave, step 4*gridDim.y
+  __shared__ float red[4][64][8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cg = blockIdx.x * 64 + lane;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (cg * 8 < N) {
+    for (int row = blockIdx.y * 4 + wave; row < M; row += gridDim.y * 4) {
+      const uint4 v = *reinterpret_cast<const uint4*>(dY + (size_t)row * ldy + cg * 8);
+      s[0] += bf16_to_f32((bf16_t)(v.x & 0xffff)); s[1] += bf16_to_f32((bf16_t)(v.x >> 16));
+      s[2] += bf16_to_f32((bf16_t)(v.y & 0xffff)); s[3] += bf16_to_f32((bf16_t)(v.y >> 16));
+      s[4] += bf16_to_f32((bf16_t)(v.z & 0xffff)); s[5] += bf16_to_f32((bf16_t)(v.z >> 16));
+      s[6] += bf16_to_f32((bf16_t)(v.w & 0xffff)); s[7] += bf16_to_f32((bf16_t)(v.w >> 16));
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[wave][lane][j] = s[j];
+  __syncthreads();
+  if (wave == 0 && cg * 8 < N) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      ws[(size_t)blockIdx.y * N + cg * 8 + j] =
+          (red[0][lane][j] + red[1][lane][j]) + (red[2][lane][j] + red[3][lane][j]);
+  }
+}
+
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ ws, int nparts, int N,
+                                                             float* db, int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= N) return;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += ws[(size_t)p * N + c];
+  db[c] = accumulate ? db[c] + s : s;
+}
+
+inline int colsum_parts(int M) {
+  int p = (M + 3) / 4;
+  return p > CS_ROWBLOCKS ? CS_ROWBLOCKS : p;
+}
+
+}  // namespace
+
+extern "C" size_t lc2is_gemm_tn_workspace_bytes(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const TnPlan p = tn_plan(M, N, K);
+  return p.splits > 1 ? (size_t)p.splits * N * K * sizeof(float) : 0;
+}
+
+extern "C" int lc2is_gemm_tn_bf16(const void* dY, int ldy, const void* X, int ldx, float* dW, int ldw, int M,
+                                  int N, int K, int accumulate, void* workspace, size_t workspace_bytes,
+                                  lc2is_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!dY || !X || !dW) return LC2IS_ERR_NULL;
+  if (M <= 0 || N <= 0 || K <= 0 || N % 8 || K % 8) return LC2IS_ERR_SHAPE;
+  if (ldy < N || ldx < K || ldw < K || ldy % 8 || ldx % 8 || ldw % 4) return LC2IS_ERR_SHAPE;
+  if ((double)(M + 64) * ldy * 2.0 >= 2147483648.0 || (double)(M + 64) * ldx * 2.0 >= 2147483648.0)
+    return LC2IS_ERR_UNSUPPORTED;
+  const TnPlan p = tn_plan(M, N, K);
+  const size_t need = lc2is_gemm_tn_workspace_bytes(M, N, K);
+  if (need && (!workspace || workspace_bytes < need)) return LC2IS_ERR_WORKSPACE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            2 * TN_STAGE) != hipSuccess)
+      return LC2IS_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int grid = p.ntn * p.ntk * p.splits;
+  if (p.splits == 1) {
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(grid), dim3(256), 2 * TN_STAGE, stream, (const bf16_t*)dY, ldy,
+                       (const bf16_t*)X, ldx, dW, ldw, (size_t)0, M, N, K, p.ntn, p.ntk, p.chunk, accumulate);
+    return lc2is_check_launch();
+  }
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(grid), dim3(256), 2 * TN_STAGE, stream, (const bf16_t*)dY, ldy,
+                     (const bf16_t*)X, ldx, (float*)workspace, K, (size_t)N * K, M, N, K, p.ntn, p.ntk,
+                     p.chunk, 0);
+  int rc = lc2is_check_launch();
+  if (rc) return rc;
+  const size_t total4 = (size_t)N * K / 4;
+  int rgrid = (int)((total4 + 255) / 256);
+  if (rgrid > 2048) rgrid = 2048;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(rgrid), dim3(256), 0, stream, (const float*)workspace, p.splits,
+                     (size_t)N * K, dW, ldw, N, K, accumulate);
+  return lc2is_check_launch();
+}
+
+extern "C" size_t lc2is_colsum_workspace_bytes(int M, int N) {
+  if (M <= 0 || N <= 0) return 0;
+  return (size_t)colsum_parts(M) * N * sizeof(float);
+}
+
+extern "C" int lc2is_colsum_bf16(const void* dY, int ldy, float* db, int M, int N, int accumulate,
+                                 void* workspace, size_t workspace_bytes, lc2is_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!dY || !db) return LC2IS_ERR_NULL;
+  if (M <= 0 || N <= 0 || N % 8 || ldy < N || ldy % 8) return LC2IS_ERR_SHAPE;
+  if (!workspace || workspace_bytes < lc2is_colsum_workspace_bytes(M, N)) return LC2IS_ERR_WORKSPACE;
+  const int parts = colsum_parts(M);
+  hipLaunchKernelGGL(colsum_kernel, dim3((N / 8 + 63) / 64, parts), dim3(256), 0, stream, (const bf16_t*)dY,
+                     ldy, (float*)workspace, M, N);
+  int rc = lc2is_check_launch();
+  if (rc) return rc;
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, stream,
+                     (const float*)workspace, parts, N, db, accumulate);
+  return lc2is_check_launch();
+}

@@ -1,0 +1,244 @@
+// LayerNorm forward / backward over the fp32 residual stream (gfx950).
+// One wave64 per row; a row of C <= 2048 floats lives in registers as up to 8 float4 per lane
+// (16-byte coalesced loads, 1 KiB per wave instruction), statistics by wave shuffles — HBM-bound,
+// no LDS needed on the forward.  Backward folds the residual-path gradient add into the same pass and
+// writes the new gradient stream both as fp32 (residual chain) and bf16 (operand of the next dgrad /
+// wgrad MFMA GEMMs), and reduces dgamma/dbeta deterministically via per-block partials.
+// replaces: nn.LayerNorm at hf:modeling_clip.py:362-383 (layer_norm1/2), :604-607 (pre_layrnorm),
+//           final_layer_norm (hf CLIPTextModel), norm1-3 of model/decoder.py:9 DecoderLayer.
+#include "common.h"
+#include "lc2is_hip.h"
+
+namespace {
+
+constexpr int LN_MAXV = 8;  // float4 per lane -> C <= 2048 (kernels are instantiated for NV = 1,2,3,4,6,8)
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int ldx,
+                                                      const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, bf16_t* y, int ldy,
+                                                      float* yf, int ldyf, float* mean_out, float* rstd_out,
+                                                      int M, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int C4 = C >> 2;
+  const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * ldx);
+  float4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c4 = lane + 64 * i;
+    if (c4 < C4) {
+      v[i] = xr[c4];
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    } else {
+      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c4 = lane + 64 * i;
+    if (c4 < C4) {
+      const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+  if (lane == 0) {
+    if (mean_out) mean_out[row] = mean;
+    if (rstd_out) rstd_out[row] = rstd;
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c4 = lane + 64 * i;
+    if (c4 < C4) {
+      const float4 gm = reinterpret_cast<const float4*>(gamma)[c4];
+      float4 o;
+      o.x = (v[i].x - mean) * rstd * gm.x;
+      o.y = (v[i].y - mean) * rstd * gm.y;
+      o.z = (v[i].z - mean) * rstd * gm.z;
+      o.w = (v[i].w - mean) * rstd * gm.w;
+      if (beta) {
+        const float4 bt = reinterpret_cast<const float4*>(beta)[c4];
+        o.x += bt.x; o.y += bt.y; o.z += bt.z; o.w += bt.w;
+      }
+      if (y) {
+        uint2 pk = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
+        *reinterpret_cast<uint2*>(y + (size_t)row * ldy + 4 * c4) = pk;
+      }
+      if (yf) *reinterpret_cast<float4*>(yf + (size_t)row * ldyf + 4 * c4) = o;
+    }
+  }
+}
+
+__device__ __forceinline__ float4 load_dy4(const bf16_t* dyb, const float* dyf, size_t off) {
+  if (dyf) return *reinterpret_cast<const float4*>(dyf + off);
+  const uint2 pk = *reinterpret_cast<const uint2*>(dyb + off);
+  return make_float4(bf16_to_f32((bf16_t)(pk.x & 0xffff)), bf16_to_f32((bf16_t)(pk.x >> 16)),
+                     bf16_to_f32((bf16_t)(pk.y & 0xffff)), bf16_to_f32((bf16_t)(pk.y >> 16)));
+}
+
+// grid = nblk blocks of 4 waves; wave w of block b walks rows b*4+w, +4*nblk, ...
+// partial dgamma/dbeta per block -> ws[b][0][C], ws[b][1][C]
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dyb, int lddy,
+                                                      const float* __restrict__ dyf, int lddyf,
+                                                      const float* __restrict__ x, int ldx,
+                                                      const float* __restrict__ gamma,
+                                                      const float* __restrict__ mean,
+                                                      const float* __restrict__ rstd,
+                                                      const float* __restrict__ dres, int lddres,
+                                                      float* dxf, int lddx, bf16_t* dxb, int lddxb,
+                                                      float* ws, int M, int C) {
+  __shared__ float red[4 * 2048];  // [wave][C <= 2048], reused for dgamma then dbeta
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int C4 = C >> 2;
+  float4 gm[NV], dg[NV], db[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c4 = lane + 64 * i;
+    gm[i] = (c4 < C4) ? reinterpret_cast<const float4*>(gamma)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    dg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int ldy_ = dyf ? lddyf : lddy;
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    const float mu = mean[row], rs = rstd[row];
+    float4 xh[NV], dy[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c4 = lane + 64 * i;
+      if (c4 < C4) {
+        const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)row * ldx + 4 * c4);
+        dy[i] = load_dy4(dyb, dyf, (size_t)row * ldy_ + 4 * c4);
+        xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+        const float a = dy[i].x * gm[i].x, b = dy[i].y * gm[i].y, c = dy[i].z * gm[i].z, d = dy[i].w * gm[i].w;
+        s1 += (a + b) + (c + d);
+        s2 += (a * xh[i].x + b * xh[i].y) + (c * xh[i].z + d * xh[i].w);
+        dg[i].x += dy[i].x * xh[i].x; dg[i].y += dy[i].y * xh[i].y;
+        dg[i].z += dy[i].z * xh[i].z; dg[i].w += dy[i].w * xh[i].w;
+        db[i].x += dy[i].x; db[i].y += dy[i].y; db[i].z += dy[i].z; db[i].w += dy[i].w;
+      }
+    }
+    const float c1 = wave_sum(s1) / (float)C, c2 = wave_sum(s2) / (float)C;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c4 = lane + 64 * i;
+      if (c4 < C4) {
+        float4 o;
+        o.x = rs * (dy[i].x * gm[i].x - c1 - xh[i].x * c2);
+        o.y = rs * (dy[i].y * gm[i].y - c1 - xh[i].y * c2);
+        o.z = rs * (dy[i].z * gm[i].z - c1 - xh[i].z * c2);
+        o.w = rs * (dy[i].w * gm[i].w - c1 - xh[i].w * c2);
+        if (dres) {
+          const float4 r = *reinterpret_cast<const float4*>(dres + (size_t)row * lddres + 4 * c4);
+          o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
+        if (dxf) *reinterpret_cast<float4*>(dxf + (size_t)row * lddx + 4 * c4) = o;
+        if (dxb) {
+          uint2 pk = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
+          *reinterpret_cast<uint2*>(dxb + (size_t)row * lddxb + 4 * c4) = pk;
+        }
+      }
+    }
+  }
+  // combine the 4 waves' column partials through LDS in two rounds (dgamma, then dbeta) to stay
+  // inside 4 x 2048 floats = 32 KiB: red viewed as [4][2048]
+  float* r = red;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c4 = lane + 64 * i;
+      if (c4 < C4) *reinterpret_cast<float4*>(r + wave * 2048 + 4 * c4) = pass ? db[i] : dg[i];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+      const float t = (r[c] + r[2048 + c]) + (r[4096 + c] + r[6144 + c]);
+      ws[((size_t)blockIdx.x * 2 + pass) * C + c] = t;
+    }
+  }
+}
+
+// out[c] (+)= sum_b ws[b][which][c]; grid over columns
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ ws, int nblk, int C,
+                                                             float* dgamma, float* dbeta, int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float g = 0.f, b = 0.f;
+  for (int k = 0; k < nblk; ++k) {
+    g += ws[((size_t)k * 2 + 0) * C + c];
+    b += ws[((size_t)k * 2 + 1) * C + c];
+  }
+  if (dgamma) dgamma[c] = accumulate ? dgamma[c] + g : g;
+  if (dbeta) dbeta[c] = accumulate ? dbeta[c] + b : b;
+}
+
+inline int ln_bwd_blocks(int M) {
+  int nb = (M + 3) / 4;
+  return nb > 512 ? 512 : nb;
+}
+
+}  // namespace
+
+extern "C" int lc2is_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta,
+                                   void* y_bf16, int ldy, float* y_f32, int ldyf, float* mean, float* rstd,
+                                   int M, int C, float eps, lc2is_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!x || !gamma || (!y_bf16 && !y_f32)) return LC2IS_ERR_NULL;
+  if (M <= 0 || C <= 0 || C % 4 || C > LN_MAXV * 256) return LC2IS_ERR_SHAPE;
+  if (ldx < C || ldx % 4 || (y_bf16 && (ldy < C || ldy % 4)) || (y_f32 && (ldyf < C || ldyf % 4)))
+    return LC2IS_ERR_SHAPE;
+#define LN_FWD(NV_)                                                                                  \
+  hipLaunchKernelGGL(ln_fwd_kernel<NV_>, dim3((M + 3) / 4), dim3(256), 0, stream, x, ldx, gamma, beta, \
+                     (bf16_t*)y_bf16, ldy, y_f32, ldyf, mean, rstd, M, C, eps)
+  const int nv = (C / 4 + 63) / 64;
+  if (nv <= 1) LN_FWD(1); else if (nv == 2) LN_FWD(2); else if (nv == 3) LN_FWD(3);
+  else if (nv == 4) LN_FWD(4); else if (nv <= 6) LN_FWD(6); else LN_FWD(8);
+#undef LN_FWD
+  return lc2is_check_launch();
+}
+
+extern "C" size_t lc2is_layernorm_bwd_workspace_bytes(int M, int C) {
+  if (M <= 0 || C <= 0) return 0;
+  return (size_t)ln_bwd_blocks(M) * 2 * (size_t)C * sizeof(float);
+}
+
+extern "C" int lc2is_layernorm_bwd(const void* dy_bf16, int lddy, const float* dy_f32, int lddyf,
+                                   const float* x, int ldx, const float* gamma, const float* mean,
+                                   const float* rstd, const float* dres, int lddres, float* dx_f32, int lddx,
+                                   void* dx_bf16, int lddxb, float* dgamma, float* dbeta, int accumulate,
+                                   int M, int C, void* workspace, size_t workspace_bytes,
+                                   lc2is_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if ((!dy_bf16 && !dy_f32) || !x || !gamma || !mean || !rstd || (!dx_f32 && !dx_bf16)) return LC2IS_ERR_NULL;
+  if (M <= 0 || C <= 0 || C % 4 || C > LN_MAXV * 256) return LC2IS_ERR_SHAPE;
+  if (ldx < C || ldx % 4) return LC2IS_ERR_SHAPE;
+  if ((dy_f32 ? (lddyf < C || lddyf % 4) : (lddy < C || lddy % 4))) return LC2IS_ERR_SHAPE;
+  if ((dres && (lddres < C || lddres % 4)) || (dx_f32 && (lddx < C || lddx % 4)) ||
+      (dx_bf16 && (lddxb < C || lddxb % 4)))
+    return LC2IS_ERR_SHAPE;
+  if (!workspace || workspace_bytes < lc2is_layernorm_bwd_workspace_bytes(M, C)) return LC2IS_ERR_WORKSPACE;
+  const int nblk = ln_bwd_blocks(M);
+#define LN_BWD(NV_)                                                                                   \
+  hipLaunchKernelGGL(ln_bwd_kernel<NV_>, dim3(nblk), dim3(256), 0, stream, (const bf16_t*)dy_bf16, lddy, \
+                     dy_f32, lddyf, x, ldx, gamma, mean, rstd, dres, lddres, dx_f32, lddx,              \
+                     (bf16_t*)dx_bf16, lddxb, (float*)workspace, M, C)
+  const int nv = (C / 4 + 63) / 64;
+  if (nv <= 1) LN_BWD(1); else if (nv == 2) LN_BWD(2); else if (nv == 3) LN_BWD(3);
+  else if (nv == 4) LN_BWD(4); else if (nv <= 6) LN_BWD(6); else LN_BWD(8);
+#undef LN_BWD
+  int rc = lc2is_check_launch();
+  if (rc) return rc;
+  if (dgamma || dbeta) {
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, stream,
+                       (const float*)workspace, nblk, C, dgamma, dbeta, accumulate);
+    rc = lc2is_check_launch();
+  }
+  return rc;
+}

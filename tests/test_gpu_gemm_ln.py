@@ -1,0 +1,137 @@
+"""GPU parity of the dense-layer and LayerNorm kernels against plain fp32/fp64 PyTorch (through the C ABI)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+def _rel(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("M,N,K,cfg", [
+    (300, 192, 128, 1), (300, 192, 128, 2), (300, 192, 128, 3), (1025, 768, 768, 0), (4100, 2304, 768, 0),
+    (129, 152, 512, 0), (77, 64, 64, 3), (2050, 768, 3072, 2),
+])
+def test_gemm_nt_plain(dev, M, N, K, cfg):
+    from lc2is_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N)
+    a = _bf(torch.randn(M, K, generator=g)).to(dev)
+    w = _bf(torch.randn(N, K, generator=g) * 0.05).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    ob, of, _ = ops.gemm_nt(a, w, bias, out_bf16=True, out_f32=True, tile_cfg=cfg)
+    ref = a.double() @ w.double().T + bias.double()
+    assert _rel(of, ref) < 2e-6 * (K ** 0.5)  # fp32 accumulate of exact bf16 products
+    assert (of.double() - ref).abs().max().item() < 1e-3
+    assert _rel(ob.float(), ref) < 4e-3  # bf16 output rounding (2^-9 relative)
+
+
+def test_gemm_nt_asymmetric_identity(dev):
+    """A = I against an asymmetric W catches a transposed C write (guide §3)."""
+    from lc2is_amd import ops
+    K = 128
+    a = torch.eye(K, dtype=torch.bfloat16, device=dev)
+    w = _bf(torch.arange(192 * K, dtype=torch.float32).reshape(192, K) % 251 - 125.0).to(dev)
+    _, of, _ = ops.gemm_nt(a, w, None, out_bf16=None, out_f32=True)
+    assert torch.equal(of, w.float().T.contiguous())
+
+
+@pytest.mark.parametrize("act", ["quick_gelu", "relu"])
+def test_gemm_nt_activation_and_backward_epilogue(dev, act):
+    from lc2is_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(5)
+    M, N, K = 515, 384, 192
+    a = _bf(torch.randn(M, K, generator=g)).to(dev)
+    w = _bf(torch.randn(N, K, generator=g) * 0.1).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    resid = torch.randn(M, N, generator=g).to(dev)
+    code = ops.ACT_QUICK_GELU if act == "quick_gelu" else ops.ACT_RELU
+    ob, of, z = ops.gemm_nt(a, w, bias, act=code, resid=resid, out_bf16=True, out_f32=True, aux_out=True)
+    zr = a.double() @ w.double().T + bias.double()
+    ar = zr * torch.sigmoid(1.702 * zr) if act == "quick_gelu" else zr.clamp_min(0)
+    assert _rel(z.float(), zr) < 4e-3
+    assert _rel(of, ar + resid.double()) < 1e-5
+    # backward epilogue: dz = (dy @ w2) * act'(saved)
+    dy = _bf(torch.randn(M, K, generator=g)).to(dev)
+    saved = z if act == "quick_gelu" else ob  # relu saves its output
+    dcode = ops.ACT_DQUICK_GELU if act == "quick_gelu" else ops.ACT_DRELU
+    dz, _, _ = ops.gemm_nt(dy, w, None, act=dcode, aux_in=saved)
+    s = saved.double()
+    if act == "quick_gelu":
+        sg = torch.sigmoid(1.702 * s)
+        d = sg * (1 + 1.702 * s * (1 - sg))
+    else:
+        d = (s > 0).double()
+    ref = (dy.double() @ w.double().T) * d
+    assert _rel(dz.float(), ref) < 5e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 128, 128), (1025, 768, 768), (4100, 2304, 768), (2050, 152, 512),
+                                   (64, 64, 64), (5000, 3072, 768), (33, 8, 8)])
+def test_gemm_tn(dev, M, N, K):
+    from lc2is_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    dy = _bf(torch.randn(M, N, generator=g)).to(dev)
+    x = _bf(torch.randn(M, K, generator=g)).to(dev)
+    dw = ops.gemm_tn(dy, x)
+    ref = dy.double().T @ x.double()
+    assert _rel(dw, ref) < 1e-5
+    dw2 = ops.gemm_tn(dy, x, dw.clone(), accumulate=True)
+    assert _rel(dw2, 2 * ref) < 1e-5
+    # bitwise reproducible
+    assert torch.equal(ops.gemm_tn(dy, x), dw)
+
+
+def test_gemm_tn_asymmetric(dev):
+    from lc2is_amd import ops
+    M = 128
+    dy = torch.eye(M, dtype=torch.bfloat16, device=dev)[:, :64].contiguous()  # [M,64]: dW[n] = x[n]
+    x = _bf((torch.arange(M * 192, dtype=torch.float32).reshape(M, 192) % 253) - 126.0).to(dev)
+    dw = ops.gemm_tn(dy, x)
+    assert torch.equal(dw, x.float()[:64])
+
+
+def test_colsum(dev):
+    from lc2is_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(3)
+    dy = _bf(torch.randn(4100, 2304, generator=g)).to(dev)
+    db = ops.colsum(dy)
+    assert _rel(db, dy.double().sum(0)) < 1e-5
+    v = dy[:, 768:1536]  # strided view
+    assert _rel(ops.colsum(v), v.double().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("M,C", [(1025, 768), (37, 64), (513, 512), (260, 1024), (100, 192), (9, 2048)])
+def test_layernorm_fwd_bwd(dev, M, C):
+    from lc2is_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(C + M)
+    x = (torch.randn(M, C, generator=g) * 2 + 0.5).to(dev)
+    gamma = (1 + 0.1 * torch.randn(C, generator=g)).to(dev)
+    beta = (0.1 * torch.randn(C, generator=g)).to(dev)
+    yb, yf, mean, rstd = ops.layernorm_fwd(x, gamma, beta, 1e-5, out_bf16=True, out_f32=True)
+    xd = x.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xd, (C,), gd, bd, 1e-5)
+    assert (yf.double() - ref).abs().max().item() < 2e-5
+    assert _rel(yb.float(), ref) < 4e-3
+    # no-bias variant (torch 2.10 bias=False drift of DecoderLayer norms)
+    _, yf2, _, _ = ops.layernorm_fwd(x, gamma, None, 1e-5, out_bf16=None, out_f32=True)
+    assert (yf2.double() - (ref - bd)).abs().max().item() < 2e-5
+    dy = torch.randn(M, C, generator=g).to(dev)
+    dres = torch.randn(M, C, generator=g).to(dev)
+    ref.backward(dy.double())
+    dxf, dxb, dg, db = ops.layernorm_bwd(dy, x, gamma, mean, rstd, dres=dres)
+    assert _rel(dxf, xd.grad + dres.double()) < 1e-5
+    assert _rel(dxb.float(), xd.grad + dres.double()) < 4e-3
+    assert _rel(dg, gd.grad) < 1e-5
+    assert _rel(db, bd.grad) < 1e-5
+    # bf16 dy path
+    dyb = _bf(dy)
+    dxf2, _, _, _ = ops.layernorm_bwd(dyb, x, gamma, mean, rstd, want_bf16=False)
+    xd.grad = None
+    torch.nn.functional.layer_norm(xd, (C,), gd, bd, 1e-5).backward(dyb.double())
+    assert _rel(dxf2, xd.grad) < 1e-5
