@@ -83,6 +83,19 @@ int lc2is_layernorm_bwd(const void* dy_bf16, int lddy, const float* dy_f32, int 
                         float* dgamma, float* dbeta, int accumulate, int M, int C, void* workspace,
                         size_t workspace_bytes, lc2is_stream_t stream);
 
+/* ---- attention -----------------------------------------------------------------------------------
+ * O[b,s,h,:] = softmax_k( scale * Q[b,s,h,:]·K[b,k,h,:] + kbias[b,k] (+ causal) ) · V[b,k,h,:]
+ * Q/K/V/O are token-major 2-D views: row (b*S + s), head h in columns [h*D,(h+1)*D), row stride ld*
+ * (elements) — Q, K, V may alias one packed projection buffer.  D in {64, 96, 128}.
+ * kbias: fp32 [B,Sk] additive key bias (0 = attend, -inf = masked; this is key_padding_mask /
+ * attention_mask), NULL = none.  causal != 0 adds the lower-triangular mask (requires Sq == Sk).
+ * lse2 (optional, fp32 [B,H,Sq]): log2-domain log-sum-exp of the scaled, masked scores, saved for backward.
+ * replaces: hf:modeling_clip.py:259-277 eager_attention_forward (+ :298-335), and the attention core of
+ *   torch:nn/functional.py multi_head_attention_forward used by model/decoder.py:9-21. */
+int lc2is_attention_fwd(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O,
+                        int ldo, float* lse2, const float* kbias, int B, int H, int Sq, int Sk, int D,
+                        float scale, int causal, lc2is_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

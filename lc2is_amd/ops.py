@@ -26,6 +26,7 @@ _ARGTYPES = {
     "lc2is_layernorm_bwd_workspace_bytes": [_I, _I],
     "lc2is_layernorm_bwd": [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I,
                             _P, _Z, _P],
+    "lc2is_attention_fwd": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
 }
 _bound = {}
 
@@ -195,3 +196,23 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: 
                                     _ptr(ws), ws.numel(), _stream())
     _lib.check(rc, f"layernorm_bwd M={M} C={Cc}")
     return dxf, dxb, dgamma, dbeta
+
+
+def attention_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, H: int, Sq: int, Sk: int, D: int,
+                  scale: float, *, causal: bool = False, kbias: torch.Tensor | None = None,
+                  save_lse: bool = True, out: torch.Tensor | None = None):
+    """q [B*Sq, H*D], k/v [B*Sk, H*D] bf16 2-D views (any row stride).  Returns (o [B*Sq, H*D] bf16, lse2)."""
+    _chk(q, torch.bfloat16, "q"); _chk(k, torch.bfloat16, "k"); _chk(v, torch.bfloat16, "v")
+    _chk(kbias, torch.float32, "kbias")
+    if q.shape != (B * Sq, H * D) or k.shape != (B * Sk, H * D) or v.shape != (B * Sk, H * D):
+        raise RuntimeError("lc2is_amd.attention_fwd: q/k/v shapes do not match B,H,S,D")
+    if kbias is not None and (kbias.shape != (B, Sk) or not kbias.is_contiguous()):
+        raise RuntimeError("lc2is_amd.attention_fwd: kbias must be contiguous [B,Sk]")
+    o = out if out is not None else torch.empty((B * Sq, H * D), dtype=torch.bfloat16, device=q.device)
+    _chk(o, torch.bfloat16, "out")
+    lse = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device) if save_lse else None
+    rc = _fn("lc2is_attention_fwd")(_ptr(q), _ld(q), _ptr(k), _ld(k), _ptr(v), _ld(v), _ptr(o), _ld(o),
+                                    _ptr(lse), _ptr(kbias), B, H, Sq, Sk, D, float(scale), int(causal),
+                                    _stream())
+    _lib.check(rc, f"attention_fwd B={B} H={H} Sq={Sq} Sk={Sk} D={D}")
+    return o, lse

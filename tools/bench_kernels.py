@@ -21,8 +21,20 @@ def timeit(fn, iters=20, warm=3):
     return e0.elapsed_time(e1) / iters * 1e-3
 
 
+def bench_attention(dev):
+    for (B, H, S, D) in [(32, 12, 1025, 64), (32, 8, 1024, 96)]:
+        qkv = torch.randn(B * S, 3 * H * D, device=dev).bfloat16()
+        q, k, v = qkv[:, :H * D], qkv[:, H * D:2 * H * D], qkv[:, 2 * H * D:]
+        o = torch.empty(B * S, H * D, dtype=torch.bfloat16, device=dev)
+        t = timeit(lambda: ops.attention_fwd(q, k, v, B, H, S, S, D, D ** -0.5, out=o))
+        print(f"attention_fwd B={B} H={H} S={S} D={D}: {t*1e6:8.1f} us  {4*B*H*S*S*D/t/1e12:7.1f} TF/s", flush=True)
+
+
 def main():
     dev = torch.device("cuda:0")
+    import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "attn":
+        return bench_attention(dev)
     M = 32 * 1025
     for (N, K) in [(2304, 768), (768, 768), (3072, 768), (768, 3072)]:
         a = torch.randn(M, K, device=dev).bfloat16()
