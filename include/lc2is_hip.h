@@ -96,6 +96,15 @@ int lc2is_attention_fwd(const void* Q, int ldq, const void* K, int ldk, const vo
                         int ldo, float* lse2, const float* kbias, int B, int H, int Sq, int Sk, int D,
                         float scale, int causal, lc2is_stream_t stream);
 
+/* Backward of lc2is_attention_fwd: dQ, dK, dV (bf16, same 2-D strided views as Q/K/V — they may alias one
+ * packed dQKV buffer) from dO, the forward's O and lse2.  `delta` is fp32 [B,H,Sq] scratch (rowsum(dO*O)).
+ * Two launches (dQ; then dK/dV), no atomics: bitwise reproducible.
+ * replaces: autograd of the attention cores above (reference engine.py:100 loss.backward()). */
+int lc2is_attention_bwd(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
+                        const void* O, int ldo, const void* dO, int lddo, void* dQ, int lddq, void* dK,
+                        int lddk, void* dV, int lddv, const float* lse2, float* delta, const float* kbias,
+                        int B, int H, int Sq, int Sk, int D, float scale, int causal, lc2is_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

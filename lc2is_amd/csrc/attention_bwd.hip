@@ -1,0 +1,466 @@
+// Fused attention backward (flash-style: P is recomputed from Q, K and the forward's log-sum-exp).
+// replaces: autograd of hf eager_attention_forward (hf:modeling_clip.py:259-277) and of torch
+//   multi_head_attention_forward's attention core (model/decoder.py:9-21), reached from loss.backward()
+//   (reference engine.py:100).
+//
+// Two launches, no atomics, bitwise reproducible:
+//   (1) dQ kernel — "query on the lane" (same orientation as the forward): per 64-key tile
+//       S^T = K·Q^T, dP^T = V·dO^T, dS^T = P^T∘(dP^T − δ), dQ^T[d][q] += K^T·dS^T.  δ = rowsum(dO∘O) is
+//       computed in this kernel's prologue (each lane owns one query row) and written out for (2).
+//   (2) dK/dV kernel — "key on the lane": a wave owns 32 keys (K, V fragments live in registers for the whole
+//       kernel), and sweeps the queries: S = Q·K^T, dP = dO·V^T, then dV^T[d][key] += dO^T·P and
+//       dK^T[d][key] += Q^T·dS take the fp32 accumulators of S/dP, packed to bf16, directly as MFMA B
+//       operands (accumulator-as-operand), so nothing but the shared Q/dO tiles touches LDS.
+// The shared tiles are read BOTH by rows (ds_read_b128, MFMA A operand of S/dP) and by columns
+// (ds_read_b64_tr_b16, A operand of the transposed products) from ONE LDS image, made conflict-free for
+// both by an XOR swizzle of the 16-byte chunk index (128-byte rows for D=64, 256-byte rows otherwise).
+#include "common.h"
+#include "lc2is_hip.h"
+
+namespace {
+
+struct AttnBwdArgs {
+  const bf16_t* Q; int ldq;
+  const bf16_t* K; int ldk;
+  const bf16_t* V; int ldv;
+  const bf16_t* O; int ldo;
+  const bf16_t* dO; int lddo;
+  bf16_t* dQ; int lddq;
+  bf16_t* dK; int lddk;
+  bf16_t* dV; int lddv;
+  const float* lse2;   // [B,H,Sq]
+  float* delta;        // [B,H,Sq]  written by the dQ kernel, read by the dK/dV kernel
+  const float* kbias;  // [B,Sk] or null
+  int B, H, Sq, Sk;
+  float scale, scale_log2;
+  int causal;
+};
+
+constexpr float LOG2E = 1.44269504088896341f;
+
+template <int D> struct Img {
+  static constexpr int PITCH = (D == 64) ? 128 : 256;
+  static constexpr int TILE = 64 * PITCH;
+  static constexpr int CH = D / 8;
+  static constexpr int NCH = 64 * CH / 256;
+  // byte offset of 16-byte chunk `ch` of row `row`
+  __device__ static __forceinline__ int off(int row, int ch) {
+    if constexpr (D == 64) {
+      return row * 128 + ((ch ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3))) << 4);
+    } else {
+      return row * 256 + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
+    }
+  }
+};
+
+__device__ __forceinline__ bf16x8_t tr_frag3(const char* base, int addr_lo, int addr_hi) {
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4_t*)LDS_PTR(base + addr_lo));
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4_t*)LDS_PTR(base + addr_hi));
+  s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+__device__ __forceinline__ bf16x8_t pack8(const f32x16_t& v, int base) {
+  bf16x8_t r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (__bf16)v[base + j];
+  return r;
+}
+
+__device__ __forceinline__ float dot8(const i32x4_t& a, const i32x4_t& b) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned x = (unsigned)a[i], y = (unsigned)b[i];
+    s += bf16_to_f32((bf16_t)(x & 0xffff)) * bf16_to_f32((bf16_t)(y & 0xffff));
+    s += bf16_to_f32((bf16_t)(x >> 16)) * bf16_to_f32((bf16_t)(y >> 16));
+  }
+  return s;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// (1) dQ kernel: grid (ceil(Sq/128), H, B), 4 waves x 32 queries; loops over 64-key tiles.
+// ------------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs p) {
+  using I = Img<D>;
+  constexpr int NKS = D / 16, NDT = D / 32, CH = I::CH, NCH = I::NCH;
+  constexpr int STAGE = 2 * I::TILE + 256;  // K image, V image, 64 bias floats
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int hh = lane >> 5, l31 = lane & 31;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int qrow = blockIdx.x * 128 + wid * 32 + l31;
+  const bool qok = qrow < p.Sq;
+  const float INF = __builtin_inff();
+
+  int nkt = (p.Sk + 63) / 64;
+  if (p.causal) {
+    const int lim = (blockIdx.x * 128 + 128 + 63) / 64;
+    if (lim < nkt) nkt = lim;
+  }
+
+  const __amdgpu_buffer_rsrc_t rsQ = make_rsrc(p.Q, (unsigned)p.B * p.Sq * p.ldq * 2u);
+  const __amdgpu_buffer_rsrc_t rsO = make_rsrc(p.O, (unsigned)p.B * p.Sq * p.ldo * 2u);
+  const __amdgpu_buffer_rsrc_t rsdO = make_rsrc(p.dO, (unsigned)p.B * p.Sq * p.lddo * 2u);
+  const __amdgpu_buffer_rsrc_t rsK = make_rsrc(p.K, (unsigned)p.B * p.Sk * p.ldk * 2u);
+  const __amdgpu_buffer_rsrc_t rsV = make_rsrc(p.V, (unsigned)p.B * p.Sk * p.ldv * 2u);
+
+  bf16x8_t qf[NKS], dof[NKS];
+  float dpart = 0.f;
+  {
+    const int tok = b * p.Sq + qrow;
+    const int qo = qok ? (tok * p.ldq + head * D + 8 * hh) * 2 : -1;
+    const int oo = qok ? (tok * p.ldo + head * D + 8 * hh) * 2 : -1;
+    const int go = qok ? (tok * p.lddo + head * D + 8 * hh) * 2 : -1;
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+      const i32x4_t qv = __builtin_amdgcn_raw_buffer_load_b128(rsQ, qok ? qo + s * 32 : -1, 0, 0);
+      const i32x4_t ov = __builtin_amdgcn_raw_buffer_load_b128(rsO, qok ? oo + s * 32 : -1, 0, 0);
+      const i32x4_t gv = __builtin_amdgcn_raw_buffer_load_b128(rsdO, qok ? go + s * 32 : -1, 0, 0);
+      qf[s] = __builtin_bit_cast(bf16x8_t, qv);
+      dof[s] = __builtin_bit_cast(bf16x8_t, gv);
+      dpart += dot8(ov, gv);
+    }
+  }
+  const float delta = dpart + __shfl_xor(dpart, 32, 64);
+  float lse = INF;  // padded query rows: exp2(x - inf) = 0
+  if (qok) {
+    const size_t si = ((size_t)b * p.H + head) * p.Sq + qrow;
+    const float l = p.lse2[si];
+    lse = (l == -INF) ? INF : l;
+    if (hh == 0) p.delta[si] = delta;
+  }
+
+  int k_goff[NCH], v_goff[NCH], t_lds[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = tid + i * 256, row = c / CH, ch = c % CH;
+    k_goff[i] = ((b * p.Sk + row) * p.ldk + head * D + ch * 8) * 2;
+    v_goff[i] = ((b * p.Sk + row) * p.ldv + head * D + ch * 8) * 2;
+    t_lds[i] = I::off(row, ch);
+  }
+  i32x4_t rk[NCH], rv[NCH];
+  float rbias = 0.f;
+  auto gload = [&](int kt) {
+    const int kb = kt * 64 * p.ldk * 2, vb = kt * 64 * p.ldv * 2;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      rk[i] = __builtin_amdgcn_raw_buffer_load_b128(rsK, k_goff[i] + kb, 0, 0);
+      rv[i] = __builtin_amdgcn_raw_buffer_load_b128(rsV, v_goff[i] + vb, 0, 0);
+    }
+    if (tid < 64) {
+      const int key = kt * 64 + tid;
+      rbias = (key < p.Sk) ? (p.kbias ? p.kbias[(size_t)b * p.Sk + key] * LOG2E : 0.f) : -INF;
+    }
+  };
+  auto lstore = [&](char* stage) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      *(i32x4_t*)(stage + t_lds[i]) = rk[i];
+      *(i32x4_t*)(stage + I::TILE + t_lds[i]) = rv[i];
+    }
+    if (tid < 64) *(float*)(stage + 2 * I::TILE + tid * 4) = rbias;
+  };
+
+  const int q4 = (lane >> 2) & 3, p4 = lane & 3, cg = (lane >> 4) & 1;
+
+  f32x16_t dq[NDT];
+#pragma unroll
+  for (int d = 0; d < NDT; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
+
+  if (nkt > 0) {
+    gload(0);
+    lstore(smem);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    const char* cur = smem + (kt & 1) * STAGE;
+    char* nxt = smem + ((kt + 1) & 1) * STAGE;
+    const bool more = (kt + 1) < nkt;
+    if (more) gload(kt + 1);
+    const float* biasv = (const float*)(cur + 2 * I::TILE);
+    const bool diag = p.causal && (kt * 64 + 63 > blockIdx.x * 128);
+
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f32x16_t st, dpt;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < NKS; ++s) {
+        const int a = I::off(32 * t + l31, 2 * s + hh);
+        const bf16x8_t kf = *(const bf16x8_t*)(cur + a);
+        const bf16x8_t vf = *(const bf16x8_t*)(cur + I::TILE + a);
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st, 0, 0, 0);
+        dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[s], dpt, 0, 0, 0);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const f32x4_t bz = *(const f32x4_t*)(biasv + 32 * t + 8 * c + 4 * hh);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float s2 = st[4 * c + j] * p.scale_log2 + bz[j] - lse;
+          if (diag) {
+            const int key = kt * 64 + 32 * t + 8 * c + 4 * hh + j;
+            if (key > qrow) s2 = -INF;
+          }
+          const float pr = __builtin_amdgcn_exp2f(s2);
+          dpt[4 * c + j] = pr * (dpt[4 * c + j] - delta);
+        }
+      }
+#pragma unroll
+      for (int s2i = 0; s2i < 2; ++s2i) {
+        const bf16x8_t dsf = pack8(dpt, 8 * s2i);
+        const int krow = 32 * t + 16 * s2i + 4 * hh + q4;
+#pragma unroll
+        for (int d = 0; d < NDT; ++d) {
+          const int e = 32 * d + 16 * cg + 4 * p4;  // element column
+          const int lo = I::off(krow, e >> 3) + (e & 7) * 2;
+          const int hi = I::off(krow + 8, e >> 3) + (e & 7) * 2;
+          const bf16x8_t ktf = tr_frag3(cur, lo, hi);
+          dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf, dq[d], 0, 0, 0);
+        }
+      }
+    }
+    if (more) lstore(nxt);
+    __syncthreads();
+  }
+
+  if (qok) {
+    bf16_t* row = p.dQ + (size_t)(b * p.Sq + qrow) * p.lddq + head * D;
+#pragma unroll
+    for (int d = 0; d < NDT; ++d)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int col = 32 * d + 8 * c + 4 * hh;
+        uint2 pk = make_uint2(pack_bf16x2(dq[d][4 * c] * p.scale, dq[d][4 * c + 1] * p.scale),
+                              pack_bf16x2(dq[d][4 * c + 2] * p.scale, dq[d][4 * c + 3] * p.scale));
+        *reinterpret_cast<uint2*>(row + col) = pk;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// (2) dK/dV kernel: grid (ceil(Sk/128), H, B), 4 waves x 32 keys; loops over 64-query tiles.
+// ------------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
+  using I = Img<D>;
+  constexpr int NKS = D / 16, NDT = D / 32, CH = I::CH, NCH = I::NCH;
+  constexpr int STAGE = 2 * I::TILE + 512;  // Q image, dO image, 64 lse2, 64 delta
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int hh = lane >> 5, l31 = lane & 31;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int kcol = blockIdx.x * 128 + wid * 32 + l31;
+  const bool kok = kcol < p.Sk;
+  const float INF = __builtin_inff();
+
+  const int nqt = (p.Sq + 63) / 64;
+  const int qt0 = p.causal ? (blockIdx.x * 128) / 64 : 0;  // earlier queries see none of these keys
+
+  const __amdgpu_buffer_rsrc_t rsQ = make_rsrc(p.Q, (unsigned)p.B * p.Sq * p.ldq * 2u);
+  const __amdgpu_buffer_rsrc_t rsdO = make_rsrc(p.dO, (unsigned)p.B * p.Sq * p.lddo * 2u);
+  const __amdgpu_buffer_rsrc_t rsK = make_rsrc(p.K, (unsigned)p.B * p.Sk * p.ldk * 2u);
+  const __amdgpu_buffer_rsrc_t rsV = make_rsrc(p.V, (unsigned)p.B * p.Sk * p.ldv * 2u);
+
+  bf16x8_t kf[NKS], vf[NKS];
+  {
+    const int tok = b * p.Sk + kcol;
+    const int ko = (tok * p.ldk + head * D + 8 * hh) * 2, vo = (tok * p.ldv + head * D + 8 * hh) * 2;
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+      kf[s] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rsK, kok ? ko + s * 32 : -1, 0, 0));
+      vf[s] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rsV, kok ? vo + s * 32 : -1, 0, 0));
+    }
+  }
+  const float bias = kok ? (p.kbias ? p.kbias[(size_t)b * p.Sk + kcol] * LOG2E : 0.f) : -INF;
+
+  int q_goff[NCH], g_goff[NCH], t_lds[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = tid + i * 256, row = c / CH, ch = c % CH;
+    q_goff[i] = ((b * p.Sq + row) * p.ldq + head * D + ch * 8) * 2;
+    g_goff[i] = ((b * p.Sq + row) * p.lddo + head * D + ch * 8) * 2;
+    t_lds[i] = I::off(row, ch);
+  }
+  i32x4_t rq[NCH], rg[NCH];
+  float rstat = 0.f;
+  auto gload = [&](int qt) {
+    const int qb = qt * 64 * p.ldq * 2, gb = qt * 64 * p.lddo * 2;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      rq[i] = __builtin_amdgcn_raw_buffer_load_b128(rsQ, q_goff[i] + qb, 0, 0);
+      rg[i] = __builtin_amdgcn_raw_buffer_load_b128(rsdO, g_goff[i] + gb, 0, 0);
+    }
+    if (tid < 128) {  // threads 0..63: lse2, 64..127: delta
+      const int q = qt * 64 + (tid & 63);
+      const size_t si = ((size_t)b * p.H + head) * p.Sq + q;
+      if (tid < 64) {
+        float l = (q < p.Sq) ? p.lse2[si] : INF;
+        rstat = (l == -INF) ? INF : l;
+      } else {
+        rstat = (q < p.Sq) ? p.delta[si] : 0.f;
+      }
+    }
+  };
+  auto lstore = [&](char* stage) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      *(i32x4_t*)(stage + t_lds[i]) = rq[i];
+      *(i32x4_t*)(stage + I::TILE + t_lds[i]) = rg[i];
+    }
+    if (tid < 128) *(float*)(stage + 2 * I::TILE + tid * 4) = rstat;
+  };
+
+  const int q4 = (lane >> 2) & 3, p4 = lane & 3, cg = (lane >> 4) & 1;
+
+  f32x16_t dkt[NDT], dvt[NDT];
+#pragma unroll
+  for (int d = 0; d < NDT; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dkt[d][r] = 0.f; dvt[d][r] = 0.f; }
+
+  if (qt0 < nqt) {
+    gload(qt0);
+    lstore(smem);
+  }
+  __syncthreads();
+
+  for (int qt = qt0; qt < nqt; ++qt) {
+    const int it = qt - qt0;
+    const char* cur = smem + (it & 1) * STAGE;
+    char* nxt = smem + ((it + 1) & 1) * STAGE;
+    const bool more = (qt + 1) < nqt;
+    if (more) gload(qt + 1);
+    const float* lsev = (const float*)(cur + 2 * I::TILE);
+    const float* delv = lsev + 64;
+    const bool diag = p.causal && (blockIdx.x * 128 + 127 > qt * 64);  // some key may exceed some query
+
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      f32x16_t sa, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sa[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < NKS; ++s) {
+        const int a = I::off(32 * u + l31, 2 * s + hh);
+        const bf16x8_t qfr = *(const bf16x8_t*)(cur + a);
+        const bf16x8_t gfr = *(const bf16x8_t*)(cur + I::TILE + a);
+        sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr, kf[s], sa, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gfr, vf[s], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const f32x4_t l4 = *(const f32x4_t*)(lsev + 32 * u + 8 * c + 4 * hh);
+        const f32x4_t d4 = *(const f32x4_t*)(delv + 32 * u + 8 * c + 4 * hh);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float s2 = sa[4 * c + j] * p.scale_log2 + bias - l4[j];
+          if (diag) {
+            const int q = qt * 64 + 32 * u + 8 * c + 4 * hh + j;
+            if (kcol > q) s2 = -INF;
+          }
+          const float pr = __builtin_amdgcn_exp2f(s2);
+          sa[4 * c + j] = pr;
+          dp[4 * c + j] = pr * (dp[4 * c + j] - d4[j]);
+        }
+      }
+#pragma unroll
+      for (int s2i = 0; s2i < 2; ++s2i) {
+        const bf16x8_t pf = pack8(sa, 8 * s2i);
+        const bf16x8_t dsf = pack8(dp, 8 * s2i);
+        const int qr = 32 * u + 16 * s2i + 4 * hh + q4;
+#pragma unroll
+        for (int d = 0; d < NDT; ++d) {
+          const int e = 32 * d + 16 * cg + 4 * p4;
+          const int lo = I::off(qr, e >> 3) + (e & 7) * 2;
+          const int hi = I::off(qr + 8, e >> 3) + (e & 7) * 2;
+          const bf16x8_t gtf = tr_frag3(cur + I::TILE, lo, hi);  // dO^T
+          const bf16x8_t qtf = tr_frag3(cur, lo, hi);            // Q^T
+          dvt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gtf, pf, dvt[d], 0, 0, 0);
+          dkt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, dsf, dkt[d], 0, 0, 0);
+        }
+      }
+    }
+    if (more) lstore(nxt);
+    __syncthreads();
+  }
+
+  if (kok) {
+    bf16_t* krow = p.dK + (size_t)(b * p.Sk + kcol) * p.lddk + head * D;
+    bf16_t* vrow = p.dV + (size_t)(b * p.Sk + kcol) * p.lddv + head * D;
+#pragma unroll
+    for (int d = 0; d < NDT; ++d)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int col = 32 * d + 8 * c + 4 * hh;
+        uint2 pk = make_uint2(pack_bf16x2(dkt[d][4 * c] * p.scale, dkt[d][4 * c + 1] * p.scale),
+                              pack_bf16x2(dkt[d][4 * c + 2] * p.scale, dkt[d][4 * c + 3] * p.scale));
+        *reinterpret_cast<uint2*>(krow + col) = pk;
+        uint2 pv = make_uint2(pack_bf16x2(dvt[d][4 * c], dvt[d][4 * c + 1]),
+                              pack_bf16x2(dvt[d][4 * c + 2], dvt[d][4 * c + 3]));
+        *reinterpret_cast<uint2*>(vrow + col) = pv;
+      }
+  }
+}
+
+template <int D>
+int launch_attn_bwd(const AttnBwdArgs& a, hipStream_t stream) {
+  using I = Img<D>;
+  constexpr int LDS_DQ = 2 * (2 * I::TILE + 256), LDS_KV = 2 * (2 * I::TILE + 512);
+  auto k1 = attn_bwd_dq_kernel<D>;
+  auto k2 = attn_bwd_dkdv_kernel<D>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_KV) != hipSuccess)
+      return LC2IS_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k1, dim3((a.Sq + 127) / 128, a.H, a.B), dim3(256), LDS_DQ, stream, a);
+  int rc = lc2is_check_launch();
+  if (rc) return rc;
+  hipLaunchKernelGGL(k2, dim3((a.Sk + 127) / 128, a.H, a.B), dim3(256), LDS_KV, stream, a);
+  return lc2is_check_launch();
+}
+
+}  // namespace
+
+extern "C" int lc2is_attention_bwd(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
+                                   const void* O, int ldo, const void* dO, int lddo, void* dQ, int lddq,
+                                   void* dK, int lddk, void* dV, int lddv, const float* lse2, float* delta,
+                                   const float* kbias, int B, int H, int Sq, int Sk, int D, float scale,
+                                   int causal, lc2is_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!Q || !K || !V || !O || !dO || !dQ || !dK || !dV || !lse2 || !delta) return LC2IS_ERR_NULL;
+  if (B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0) return LC2IS_ERR_SHAPE;
+  const int hd = H * D;
+  if (ldq < hd || ldk < hd || ldv < hd || ldo < hd || lddo < hd || lddq < hd || lddk < hd || lddv < hd)
+    return LC2IS_ERR_SHAPE;
+  if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 8 || lddo % 8 || lddq % 4 || lddk % 4 || lddv % 4)
+    return LC2IS_ERR_SHAPE;
+  if (causal && Sq != Sk) return LC2IS_ERR_UNSUPPORTED;
+  const double lim = 2147483648.0;
+  if ((double)B * (Sq + 64) * ldq * 2.0 >= lim || (double)B * (Sq + 64) * lddo * 2.0 >= lim ||
+      (double)B * (Sq + 64) * ldo * 2.0 >= lim || (double)B * (Sk + 64) * ldk * 2.0 >= lim ||
+      (double)B * (Sk + 64) * ldv * 2.0 >= lim)
+    return LC2IS_ERR_UNSUPPORTED;
+  AttnBwdArgs a{(const bf16_t*)Q, ldq, (const bf16_t*)K, ldk, (const bf16_t*)V, ldv, (const bf16_t*)O, ldo,
+                (const bf16_t*)dO, lddo, (bf16_t*)dQ, lddq, (bf16_t*)dK, lddk, (bf16_t*)dV, lddv, lse2, delta,
+                kbias, B, H, Sq, Sk, scale, scale * LOG2E, causal};
+  switch (D) {
+    case 64: return launch_attn_bwd<64>(a, stream);
+    case 96: return launch_attn_bwd<96>(a, stream);
+    case 128: return launch_attn_bwd<128>(a, stream);
+    default: return LC2IS_ERR_UNSUPPORTED;
+  }
+}

@@ -27,6 +27,8 @@ _ARGTYPES = {
     "lc2is_layernorm_bwd": [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I,
                             _P, _Z, _P],
     "lc2is_attention_fwd": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
+    "lc2is_attention_bwd": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P,
+                            _I, _I, _I, _I, _I, _F, _I, _P],
 }
 _bound = {}
 
@@ -216,3 +218,24 @@ def attention_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, H: 
                                     _stream())
     _lib.check(rc, f"attention_fwd B={B} H={H} Sq={Sq} Sk={Sk} D={D}")
     return o, lse
+
+
+def attention_bwd(q, k, v, o, do, lse2, B: int, H: int, Sq: int, Sk: int, D: int, scale: float, *,
+                  causal: bool = False, kbias: torch.Tensor | None = None, dq=None, dk=None, dv=None):
+    """Returns (dq, dk, dv) bf16; dq/dk/dv may be preallocated 2-D views (e.g. slices of a packed dQKV)."""
+    for t, n in ((q, "q"), (k, "k"), (v, "v"), (o, "o"), (do, "do")):
+        _chk(t, torch.bfloat16, n)
+    _chk(lse2, torch.float32, "lse2", 3); _chk(kbias, torch.float32, "kbias")
+    dev = q.device
+    dq = dq if dq is not None else torch.empty((B * Sq, H * D), dtype=torch.bfloat16, device=dev)
+    dk = dk if dk is not None else torch.empty((B * Sk, H * D), dtype=torch.bfloat16, device=dev)
+    dv = dv if dv is not None else torch.empty((B * Sk, H * D), dtype=torch.bfloat16, device=dev)
+    for t, n in ((dq, "dq"), (dk, "dk"), (dv, "dv")):
+        _chk(t, torch.bfloat16, n)
+    delta = torch.empty((B, H, Sq), dtype=torch.float32, device=dev)
+    rc = _fn("lc2is_attention_bwd")(_ptr(q), _ld(q), _ptr(k), _ld(k), _ptr(v), _ld(v), _ptr(o), _ld(o),
+                                    _ptr(do), _ld(do), _ptr(dq), _ld(dq), _ptr(dk), _ld(dk), _ptr(dv), _ld(dv),
+                                    _ptr(lse2), _ptr(delta), _ptr(kbias), B, H, Sq, Sk, D, float(scale),
+                                    int(causal), _stream())
+    _lib.check(rc, f"attention_bwd B={B} H={H} Sq={Sq} Sk={Sk} D={D}")
+    return dq, dk, dv

@@ -76,3 +76,40 @@ def test_attention_fwd_spiked_scores(dev):
     o, _ = ops.attention_fwd(q, k, v, B, H, S, S, D, 0.125)
     ro, _, _ = _ref_attention(q, k, v, B, H, S, S, D, 0.125, False, None)
     assert (o.double() - ro).abs().max().item() < 3e-2
+
+
+@pytest.mark.parametrize("B,H,Sq,Sk,D,causal,mask,packed", CASES)
+def test_attention_bwd(dev, B, H, Sq, Sk, D, causal, mask, packed):
+    from lc2is_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(B * 999 + Sq + D)
+    if packed:
+        qkv = (torch.randn(B * Sq, 3 * H * D, generator=g)).to(torch.bfloat16).to(dev)
+        q, k, v = qkv[:, :H * D], qkv[:, H * D:2 * H * D], qkv[:, 2 * H * D:]
+    else:
+        q = torch.randn(B * Sq, H * D, generator=g).to(torch.bfloat16).to(dev)
+        k = torch.randn(B * Sk, H * D, generator=g).to(torch.bfloat16).to(dev)
+        v = torch.randn(B * Sk, H * D, generator=g).to(torch.bfloat16).to(dev)
+    do = torch.randn(B * Sq, H * D, generator=g).to(torch.bfloat16).to(dev)
+    kbias = None
+    if mask:
+        valid = torch.randint(1, Sk + 1, (B,), generator=g)
+        kbias = torch.zeros(B, Sk)
+        for i in range(B):
+            kbias[i, valid[i]:] = float("-inf")
+        kbias = kbias.to(dev)
+    scale = 1.0 / math.sqrt(D)
+    o, lse2 = ops.attention_fwd(q, k, v, B, H, Sq, Sk, D, scale, causal=causal, kbias=kbias)
+    if packed:
+        dqkv = torch.zeros_like(qkv)
+        dq, dk, dv = dqkv[:, :H * D], dqkv[:, H * D:2 * H * D], dqkv[:, 2 * H * D:]
+        ops.attention_bwd(q, k, v, o, do, lse2, B, H, Sq, Sk, D, scale, causal=causal, kbias=kbias,
+                          dq=dq, dk=dk, dv=dv)
+    else:
+        dq, dk, dv = ops.attention_bwd(q, k, v, o, do, lse2, B, H, Sq, Sk, D, scale, causal=causal, kbias=kbias)
+    qd, kd, vd = (t.double().clone().requires_grad_(True) for t in (q, k, v))
+    ro, _, _ = _ref_attention(qd, kd, vd, B, H, Sq, Sk, D, scale, causal, kbias)
+    ro.backward(do.double())
+    for name, got, ref in (("dq", dq, qd.grad), ("dk", dk, kd.grad), ("dv", dv, vd.grad)):
+        rel = ((got.double() - ref).norm() / ref.norm().clamp_min(1e-30)).item()
+        assert rel < 1.5e-2, (name, rel)
+        assert (got.double() - ref).abs().max().item() < 0.05 * ref.abs().max().item() + 1e-3, name

@@ -28,6 +28,12 @@ def bench_attention(dev):
         o = torch.empty(B * S, H * D, dtype=torch.bfloat16, device=dev)
         t = timeit(lambda: ops.attention_fwd(q, k, v, B, H, S, S, D, D ** -0.5, out=o))
         print(f"attention_fwd B={B} H={H} S={S} D={D}: {t*1e6:8.1f} us  {4*B*H*S*S*D/t/1e12:7.1f} TF/s", flush=True)
+        _, lse = ops.attention_fwd(q, k, v, B, H, S, S, D, D ** -0.5, out=o)
+        do = torch.randn_like(o)
+        dqkv = torch.empty_like(qkv)
+        dq, dk, dv = dqkv[:, :H * D], dqkv[:, H * D:2 * H * D], dqkv[:, 2 * H * D:]
+        t = timeit(lambda: ops.attention_bwd(q, k, v, o, do, lse, B, H, S, S, D, D ** -0.5, dq=dq, dk=dk, dv=dv))
+        print(f"attention_bwd B={B} H={H} S={S} D={D}: {t*1e6:8.1f} us  {10*B*H*S*S*D/t/1e12:7.1f} TF/s (5-matmul count)", flush=True)
 
 
 def main():
