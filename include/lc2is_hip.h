@@ -29,7 +29,20 @@ extern "C" {
 #define LC2IS_ACT_DQUICK_GELU 3 /* backward: acc * quick_gelu'(aux_in)                                  */
 #define LC2IS_ACT_DRELU 4       /* backward: acc * (aux_in > 0)                                          */
 
+#define LC2IS_INTERP_BICUBIC 0  /* F.interpolate(mode="bicubic", align_corners=False), A = -0.75, border clamp */
+#define LC2IS_INTERP_BILINEAR 1 /* F.interpolate(mode="bilinear", align_corners=False)                          */
+
 typedef void* lc2is_stream_t; /* hipStream_t */
+
+/* One fp32 master weight [N,K] (contiguous) and its bf16 shadows; see lc2is_shadow_refresh. */
+typedef struct {
+  const void* src; /* fp32 [N,K]                                               */
+  void* dst;       /* bf16 [N, ld_dst]  row-major copy (forward GEMM operand), may be NULL */
+  void* dstT;      /* bf16 [K, ld_dstT] transposed copy (dgrad GEMM operand), may be NULL  */
+  int N, K, ld_dst, ld_dstT;
+  int tile_start;  /* exclusive prefix sum of ceil(N/64)*ceil(K/64) over the table          */
+  int reserved;
+} lc2is_shadow_desc;
 
 /* ABI / build identification: returns a static string "lc2is_hip <abi> gfx950". Host memory. */
 const char* lc2is_version(void);
@@ -52,7 +65,7 @@ int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw, const flo
 /* dW[N,K] (fp32) = dY[M,N]^T · X[M,K]  (weight gradient of out = X·W^T), reduced over M.
  * The M range is cut into `splits` slabs (workspace = splits*N*K fp32) summed by a second launch, so
  * the result is bitwise reproducible.  accumulate != 0 adds into dW instead of overwriting.
- * N % 16 == 0? no: N % 8 == 0 and K % 8 == 0.   replaces: autograd of the nn.Linear calls above. */
+ * N % 8 == 0 and K % 8 == 0.   replaces: autograd of the nn.Linear calls above. */
 size_t lc2is_gemm_tn_workspace_bytes(int M, int N, int K);
 int lc2is_gemm_tn_bf16(const void* dY, int ldy, const void* X, int ldx, float* dW, int ldw, int M, int N,
                        int K, int accumulate, void* workspace, size_t workspace_bytes,
@@ -64,7 +77,7 @@ int lc2is_colsum_bf16(const void* dY, int ldy, float* db, int M, int N, int accu
                       size_t workspace_bytes, lc2is_stream_t stream);
 
 /* ---- LayerNorm -----------------------------------------------------------------------------------
- * y = (x - mean)/sqrt(var + eps) * gamma + beta over the last dim C (C % 4 == 0, C <= 8192);
+ * y = (x - mean)/sqrt(var + eps) * gamma + beta over the last dim C (C % 4 == 0, C <= 2048);
  * x fp32 [M,C] (the residual stream is kept in fp32), y bf16; mean/rstd fp32 [M] saved for backward
  * (may be NULL in inference).  gamma/beta fp32, beta may be NULL (torch 2.10 bias=False drift).
  * replaces: nn.LayerNorm.forward at hf:CLIPEncoderLayer.forward:362-383, pre_layrnorm / final_layer_norm,
@@ -104,6 +117,65 @@ int lc2is_attention_bwd(const void* Q, int ldq, const void* K, int ldk, const vo
                         const void* O, int ldo, const void* dO, int lddo, void* dQ, int lddq, void* dK,
                         int lddk, void* dV, int lddv, const float* lse2, float* delta, const float* kbias,
                         int B, int H, int Sq, int Sk, int D, float scale, int causal, lc2is_stream_t stream);
+
+/* ---- glue (all single-pass, HBM-bound) --------------------------------------------------------------
+ * Refresh every bf16 weight shadow from the fp32 master copy in ONE launch: `descs` is a DEVICE array of
+ * ndesc descriptors ordered by tile_start; total_tiles = sum of tile counts.  K % 4 == 0 always, N % 4 == 0
+ * when dstT != NULL.  Several descriptors may target sub-blocks of one fused buffer (q/k/v -> [3C,C]). */
+int lc2is_shadow_refresh(const lc2is_shadow_desc* descs, int ndesc, int total_tiles, lc2is_stream_t stream);
+int lc2is_cast_f32_bf16(const float* src, int ld_src, void* dst_bf16, int ld_dst, int M, int C,
+                        lc2is_stream_t stream);
+int lc2is_transpose_bf16(const void* src, int ld_src, void* dst, int ld_dst, int R, int C,
+                         lc2is_stream_t stream);
+
+/* ViT patch embedding operand: out[(b*G*G + gy*G + gx)][c*p*p + i*p + j] = pixels[b][c][gy*p+i][gx*p+j]
+ * (bf16, G = H / patch, trailing pixels dropped like a stride-p conv); columns [3*p*p, ld_out) are zeroed.
+ * replaces: nn.Conv2d(3, C, patch, stride=patch, bias=False) im2col at hf:modeling_clip.py:202-218. */
+int lc2is_patchify(const float* pixels, void* out_bf16, int ld_out, int B, int H, int W, int patch,
+                   lc2is_stream_t stream);
+/* x[b,0] = cls + pos[0]; x[b,1+p] = patch[b*P+p] + pos[1+p]   (hf:modeling_clip.py:211-217) and backward. */
+int lc2is_vit_embed_fwd(const float* patch, int ld_patch, const float* cls, const float* pos, float* x,
+                        int ldx, int B, int P, int C, lc2is_stream_t stream);
+int lc2is_vit_embed_bwd(const float* dx, int ldx, float* dpos, float* dcls, void* dpatch_bf16, int ld_dpatch,
+                        int B, int P, int C, int accumulate, lc2is_stream_t stream);
+/* x[b*L+l] = token_embedding[ids[b,l]] + position_embedding[l]  (hf CLIPTextEmbeddings.forward) and
+ * backward (dtok via fp32 atomics into a caller-zeroed/running [vocab,C] gradient). */
+int lc2is_text_embed_fwd(const int64_t* ids, const float* tok, const float* pos, float* x, int ldx, int B,
+                         int L, int C, int vocab, lc2is_stream_t stream);
+int lc2is_text_embed_bwd(const int64_t* ids, const float* dx, int ldx, float* dtok, float* dpos, int B, int L,
+                         int C, int vocab, int accumulate, lc2is_stream_t stream);
+/* dst[b, dst_off+s, :] = src[b, src_off+s, :], s < n (fp32 rows of C, optional bf16 copy): drops / re-inserts
+ * the CLS token (`last_hidden_state[:, 1:, :]`, model/encoder.py:30). */
+int lc2is_rows_copy_f32(const float* src, int S_src, int src_off, float* dst_f32, void* dst_bf16, int S_dst,
+                        int dst_off, int B, int n, int C, lc2is_stream_t stream);
+
+/* Fused optimizer step over the flat fp32 parameter arena (n % 4 == 0).  g is multiplied by grad_scale
+ * (1/world_size for DP).  SGD: torch.optim.SGD semantics (momentum_buf may be NULL); AdamW: torch.optim.AdamW.
+ * replaces: optimizer.step() at engine.py:101. */
+int lc2is_sgd_step(float* params, const float* grads, float* momentum_buf, size_t n, float lr, float momentum,
+                   float weight_decay, float grad_scale, lc2is_stream_t stream);
+int lc2is_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float lr,
+                     float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                     lc2is_stream_t stream);
+
+/* ---- segmentation head tail ------------------------------------------------------------------------
+ * scores_lo: fp32 channels-last [B,h,w,ld] (C valid classes, ld in {64,128,192}); output grid H = h*S,
+ * W = w*S, S in {4,8,16}.  Computes upsample(mode) -> softmax CE against labels[B,H,W] (int64):
+ *   loss_sum[0] += sum of per-pixel losses, loss_sum[1] += number of counted pixels (caller zeroes both);
+ *   dscores_lo (optional, pre-zeroed, same layout) += grad_scale * U^T (softmax - onehot);
+ *   scores_hi (optional) = upsampled scores as NCHW fp32 [B,C,H,W] (the reference's `outputs`).
+ * replaces: model/model.py:41-53 (bicubic x4 + TextToPatch.visual + prototype matmul, commuted), CE at
+ *   engine.py:94, AuxiliaryLoss (model/loss.py:17-21, bilinear). */
+int lc2is_head_upsample_ce(const float* scores_lo, int ld, const int64_t* labels, float* dscores_lo,
+                           float* scores_hi, float* loss_sum, int B, int h, int w, int C, int S, int mode,
+                           long ignore_index, float grad_scale, lc2is_stream_t stream);
+/* Plain nn.CrossEntropyLoss on NCHW fp32 logits (the unfused drop-in path): forward saves per-pixel lse,
+ * backward writes dlogits = grad_scale * (*grad_scale_dev) * (softmax - onehot). */
+int lc2is_ce_nchw_fwd(const float* logits, const int64_t* labels, float* lse, float* loss_sum, int B, int C,
+                      long HW, long ignore_index, lc2is_stream_t stream);
+int lc2is_ce_nchw_bwd(const float* logits, const int64_t* labels, const float* lse, const float* grad_scale_dev,
+                      float grad_scale, float* dlogits, int B, int C, long HW, long ignore_index,
+                      lc2is_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -29,6 +29,20 @@ _ARGTYPES = {
     "lc2is_attention_fwd": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "lc2is_attention_bwd": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P,
                             _I, _I, _I, _I, _I, _F, _I, _P],
+    "lc2is_shadow_refresh": [_P, _I, _I, _P],
+    "lc2is_cast_f32_bf16": [_P, _I, _P, _I, _I, _I, _P],
+    "lc2is_transpose_bf16": [_P, _I, _P, _I, _I, _I, _P],
+    "lc2is_patchify": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "lc2is_vit_embed_fwd": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P],
+    "lc2is_vit_embed_bwd": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "lc2is_text_embed_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "lc2is_text_embed_bwd": [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
+    "lc2is_rows_copy_f32": [_P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P],
+    "lc2is_sgd_step": [_P, _P, _P, _Z, _F, _F, _F, _F, _P],
+    "lc2is_adamw_step": [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _F, _P],
+    "lc2is_head_upsample_ce": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, C.c_long, _F, _P],
+    "lc2is_ce_nchw_fwd": [_P, _P, _P, _P, _I, _I, C.c_long, C.c_long, _P],
+    "lc2is_ce_nchw_bwd": [_P, _P, _P, _P, _F, _P, _I, _I, C.c_long, C.c_long, _P],
 }
 _bound = {}
 
@@ -239,3 +253,181 @@ def attention_bwd(q, k, v, o, do, lse2, B: int, H: int, Sq: int, Sk: int, D: int
                                     int(causal), _stream())
     _lib.check(rc, f"attention_bwd B={B} H={H} Sq={Sq} Sk={Sk} D={D}")
     return dq, dk, dv
+
+
+INTERP_BICUBIC, INTERP_BILINEAR = 0, 1
+
+
+class ShadowDesc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("dstT", C.c_void_p), ("N", C.c_int), ("K", C.c_int),
+                ("ld_dst", C.c_int), ("ld_dstT", C.c_int), ("tile_start", C.c_int), ("reserved", C.c_int)]
+
+
+class ShadowTable:
+    """Device-resident descriptor table for ``lc2is_shadow_refresh`` (built once; pointers must stay valid)."""
+
+    def __init__(self, entries, device):
+        # entries: list of (src_f32 [N,K] contiguous, dst_bf16 2-D view or None, dstT_bf16 2-D view or None)
+        descs = (ShadowDesc * len(entries))()
+        start = 0
+        self._keep = []
+        for i, (src, dst, dstT) in enumerate(entries):
+            _chk(src, torch.float32, "shadow src"); _chk(dst, torch.bfloat16, "shadow dst")
+            _chk(dstT, torch.bfloat16, "shadow dstT")
+            if not src.is_contiguous():
+                raise RuntimeError("lc2is_amd: shadow source must be contiguous")
+            N, K = src.shape
+            if K % 4 or (dstT is not None and N % 4):
+                raise RuntimeError(f"lc2is_amd: shadow shape [{N},{K}] not supported")
+            if dst is not None and tuple(dst.shape) != (N, K):
+                raise RuntimeError("lc2is_amd: shadow dst shape mismatch")
+            if dstT is not None and tuple(dstT.shape) != (K, N):
+                raise RuntimeError("lc2is_amd: shadow dstT shape mismatch")
+            descs[i] = ShadowDesc(src.data_ptr(), _ptr(dst), _ptr(dstT), N, K, _ld(dst), _ld(dstT), start, 0)
+            start += ((N + 63) // 64) * ((K + 63) // 64)
+            self._keep.append((src, dst, dstT))
+        self.n = len(entries)
+        self.total_tiles = start
+        raw = bytes(descs)
+        self.dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+
+    def refresh(self):
+        rc = _fn("lc2is_shadow_refresh")(self.dev.data_ptr(), self.n, self.total_tiles, _stream())
+        _lib.check(rc, "shadow_refresh")
+
+
+def cast_bf16(src: torch.Tensor, out: torch.Tensor | None = None):
+    _chk(src, torch.float32, "src")
+    M, Cc = src.shape
+    out = out if out is not None else torch.empty((M, Cc), dtype=torch.bfloat16, device=src.device)
+    _chk(out, torch.bfloat16, "out")
+    _lib.check(_fn("lc2is_cast_f32_bf16")(_ptr(src), _ld(src), _ptr(out), _ld(out), M, Cc, _stream()), "cast")
+    return out
+
+
+def transpose_bf16(src: torch.Tensor, out: torch.Tensor | None = None):
+    _chk(src, torch.bfloat16, "src")
+    R, Cc = src.shape
+    out = out if out is not None else torch.empty((Cc, R), dtype=torch.bfloat16, device=src.device)
+    _chk(out, torch.bfloat16, "out")
+    _lib.check(_fn("lc2is_transpose_bf16")(_ptr(src), _ld(src), _ptr(out), _ld(out), R, Cc, _stream()),
+               "transpose")
+    return out
+
+
+def patchify(pixels: torch.Tensor, patch: int, kpad: int | None = None):
+    """pixels fp32 [B,3,H,W] contiguous -> bf16 [B*G*G, kpad]."""
+    _chk(pixels, torch.float32, "pixel_values", 4)
+    if not pixels.is_contiguous() or pixels.shape[1] != 3:
+        raise RuntimeError("lc2is_amd.patchify: pixel_values must be contiguous [B,3,H,W]")
+    B, _, H, W = pixels.shape
+    G = H // patch
+    k = 3 * patch * patch
+    kpad = kpad or ((k + 63) // 64) * 64
+    out = torch.empty((B * G * G, kpad), dtype=torch.bfloat16, device=pixels.device)
+    _lib.check(_fn("lc2is_patchify")(_ptr(pixels), _ptr(out), kpad, B, H, W, patch, _stream()), "patchify")
+    return out
+
+
+def vit_embed_fwd(patch_f32, cls, pos, B: int, P: int):
+    _chk(patch_f32, torch.float32, "patch"); _chk(cls, torch.float32, "cls", 1); _chk(pos, torch.float32, "pos")
+    Cc = patch_f32.shape[1]
+    x = torch.empty((B * (P + 1), Cc), dtype=torch.float32, device=patch_f32.device)
+    _lib.check(_fn("lc2is_vit_embed_fwd")(_ptr(patch_f32), _ld(patch_f32), _ptr(cls), _ptr(pos), _ptr(x), Cc, B,
+                                          P, Cc, _stream()), "vit_embed_fwd")
+    return x
+
+
+def vit_embed_bwd(dx, dpos, dcls, B: int, P: int, accumulate: bool = False):
+    _chk(dx, torch.float32, "dx"); _chk(dpos, torch.float32, "dpos"); _chk(dcls, torch.float32, "dcls", 1)
+    Cc = dx.shape[1]
+    dpatch = torch.empty((B * P, Cc), dtype=torch.bfloat16, device=dx.device)
+    _lib.check(_fn("lc2is_vit_embed_bwd")(_ptr(dx), _ld(dx), _ptr(dpos), _ptr(dcls), _ptr(dpatch), Cc, B, P, Cc,
+                                          int(accumulate), _stream()), "vit_embed_bwd")
+    return dpatch
+
+
+def text_embed_fwd(ids, tok, pos):
+    _chk(ids, torch.int64, "input_ids"); _chk(tok, torch.float32, "tok"); _chk(pos, torch.float32, "pos")
+    if not ids.is_contiguous():
+        raise RuntimeError("lc2is_amd.text_embed_fwd: input_ids must be contiguous")
+    B, L = ids.shape
+    V, Cc = tok.shape
+    x = torch.empty((B * L, Cc), dtype=torch.float32, device=tok.device)
+    _lib.check(_fn("lc2is_text_embed_fwd")(_ptr(ids), _ptr(tok), _ptr(pos), _ptr(x), Cc, B, L, Cc, V, _stream()),
+               "text_embed_fwd")
+    return x
+
+
+def text_embed_bwd(ids, dx, dtok, dpos, accumulate: bool = False):
+    """dtok must already hold the running gradient (or zeros): the scatter uses fp32 atomics."""
+    _chk(ids, torch.int64, "input_ids"); _chk(dx, torch.float32, "dx")
+    B, L = ids.shape
+    V, Cc = dtok.shape
+    _lib.check(_fn("lc2is_text_embed_bwd")(_ptr(ids), _ptr(dx), _ld(dx), _ptr(dtok), _ptr(dpos), B, L, Cc, V,
+                                           int(accumulate), _stream()), "text_embed_bwd")
+
+
+def rows_copy(src, S_src: int, src_off: int, S_dst: int, dst_off: int, B: int, n: int, *, dst_f32=None,
+              dst_bf16=None):
+    _chk(src, torch.float32, "src")
+    Cc = src.shape[1]
+    if not src.is_contiguous() or src.shape[0] != B * S_src:
+        raise RuntimeError("lc2is_amd.rows_copy: src must be contiguous [B*S_src, C]")
+    for t in (dst_f32, dst_bf16):
+        if t is not None and (not t.is_contiguous() or tuple(t.shape) != (B * S_dst, Cc)):
+            raise RuntimeError("lc2is_amd.rows_copy: dst must be contiguous [B*S_dst, C]")
+    _lib.check(_fn("lc2is_rows_copy_f32")(_ptr(src), S_src, src_off, _ptr(dst_f32), _ptr(dst_bf16), S_dst,
+                                          dst_off, B, n, Cc, _stream()), "rows_copy")
+
+
+def sgd_step(params, grads, momentum_buf, lr, momentum=0.0, weight_decay=0.0, grad_scale=1.0):
+    _chk(params, torch.float32, "params", 1); _chk(grads, torch.float32, "grads", 1)
+    _lib.check(_fn("lc2is_sgd_step")(_ptr(params), _ptr(grads), _ptr(momentum_buf), params.numel(), lr, momentum,
+                                     weight_decay, grad_scale, _stream()), "sgd_step")
+
+
+def adamw_step(params, grads, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    _chk(params, torch.float32, "params", 1); _chk(grads, torch.float32, "grads", 1)
+    _lib.check(_fn("lc2is_adamw_step")(_ptr(params), _ptr(grads), _ptr(m), _ptr(v), params.numel(), lr, beta1,
+                                       beta2, eps, weight_decay, int(step), grad_scale, _stream()), "adamw_step")
+
+
+def head_upsample_ce(scores_lo, labels, B: int, h: int, w: int, C: int, S: int, mode: int = INTERP_BICUBIC, *,
+                     want_grad: bool = False, want_scores: bool = False, want_loss: bool = True,
+                     ignore_index: int = -100, grad_scale: float = 1.0):
+    """scores_lo fp32 [B*h*w, ld].  Returns (loss_sum[2] or None, dscores_lo or None, scores_hi NCHW or None)."""
+    _chk(scores_lo, torch.float32, "scores_lo"); _chk(labels, torch.int64, "labels", 3)
+    if not scores_lo.is_contiguous():
+        raise RuntimeError("lc2is_amd.head_upsample_ce: scores_lo must be contiguous")
+    ld = scores_lo.shape[1]
+    dev = scores_lo.device
+    if labels is not None and (tuple(labels.shape) != (B, h * S, w * S) or not labels.is_contiguous()):
+        raise RuntimeError(f"lc2is_amd.head_upsample_ce: labels must be contiguous [{B},{h*S},{w*S}]")
+    loss = torch.zeros(2, dtype=torch.float32, device=dev) if want_loss else None
+    dlo = torch.zeros_like(scores_lo) if want_grad else None
+    hi = torch.empty((B, C, h * S, w * S), dtype=torch.float32, device=dev) if want_scores else None
+    rc = _fn("lc2is_head_upsample_ce")(_ptr(scores_lo), ld, _ptr(labels), _ptr(dlo), _ptr(hi), _ptr(loss), B, h,
+                                       w, C, S, mode, ignore_index, grad_scale, _stream())
+    _lib.check(rc, f"head_upsample_ce B={B} h={h} w={w} C={C} S={S}")
+    return loss, dlo, hi
+
+
+def ce_nchw_fwd(logits, labels, ignore_index: int = -100):
+    _chk(logits, torch.float32, "logits", 4); _chk(labels, torch.int64, "labels", 3)
+    if not logits.is_contiguous() or not labels.is_contiguous():
+        raise RuntimeError("lc2is_amd.ce_nchw_fwd: logits/labels must be contiguous")
+    B, Cc, H, W = logits.shape
+    lse = torch.empty((B, H, W), dtype=torch.float32, device=logits.device)
+    loss = torch.zeros(2, dtype=torch.float32, device=logits.device)
+    _lib.check(_fn("lc2is_ce_nchw_fwd")(_ptr(logits), _ptr(labels), _ptr(lse), _ptr(loss), B, Cc, H * W,
+                                        ignore_index, _stream()), "ce_nchw_fwd")
+    return loss, lse
+
+
+def ce_nchw_bwd(logits, labels, lse, grad_scale_dev, grad_scale: float, ignore_index: int = -100):
+    B, Cc, H, W = logits.shape
+    d = torch.empty_like(logits)
+    _lib.check(_fn("lc2is_ce_nchw_bwd")(_ptr(logits), _ptr(labels), _ptr(lse), _ptr(grad_scale_dev), grad_scale,
+                                        _ptr(d), B, Cc, H * W, ignore_index, _stream()), "ce_nchw_bwd")
+    return d

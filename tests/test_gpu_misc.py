@@ -1,0 +1,176 @@
+"""GPU parity of the glue kernels and the fused head (upsample + CE) against PyTorch fp32/fp64 ops."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+
+def test_shadow_refresh_and_casts(dev):
+    from lc2is_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(0)
+    ws = [torch.randn(n, k, generator=g).to(dev) for n, k in [(768, 768), (768, 768), (768, 768), (3072, 768),
+                                                              (151, 512), (100, 36)]]
+    fused = torch.zeros(2304, 768, dtype=torch.bfloat16, device=dev)
+    fusedT = torch.zeros(768, 2304, dtype=torch.bfloat16, device=dev)
+    d3 = torch.zeros(3072, 768, dtype=torch.bfloat16, device=dev)
+    d3T = torch.zeros(768, 3072, dtype=torch.bfloat16, device=dev)
+    proto = torch.zeros(192, 512, dtype=torch.bfloat16, device=dev)
+    small = torch.zeros(100, 36, dtype=torch.bfloat16, device=dev)
+    smallT = torch.zeros(36, 100, dtype=torch.bfloat16, device=dev)
+    entries = [(ws[i], fused[768 * i:768 * (i + 1)], fusedT[:, 768 * i:768 * (i + 1)]) for i in range(3)]
+    entries += [(ws[3], d3, d3T), (ws[4], proto[:151], None), (ws[5], small, smallT)]
+    tab = ops.ShadowTable(entries, dev)
+    tab.refresh()
+    ref = torch.cat(ws[:3], 0).bfloat16()
+    assert torch.equal(fused, ref) and torch.equal(fusedT, ref.T.contiguous())
+    assert torch.equal(d3, ws[3].bfloat16()) and torch.equal(d3T, ws[3].bfloat16().T.contiguous())
+    assert torch.equal(proto[:151], ws[4].bfloat16()) and proto[151:].abs().sum().item() == 0
+    assert torch.equal(small, ws[5].bfloat16()) and torch.equal(smallT, ws[5].bfloat16().T.contiguous())
+    x = torch.randn(300, 192, generator=g).to(dev)
+    assert torch.equal(ops.cast_bf16(x), x.bfloat16())
+    xb = x.bfloat16()
+    assert torch.equal(ops.transpose_bf16(xb), xb.T.contiguous())
+
+
+@pytest.mark.parametrize("B,H,ps,C", [(2, 64, 16, 192), (1, 128, 16, 768), (2, 70, 14, 64)])
+def test_patch_embedding_path(dev, B, H, ps, C):
+    from lc2is_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(1)
+    pix = torch.randn(B, 3, H, H, generator=g).to(dev)
+    w = (torch.randn(C, 3, ps, ps, generator=g) * 0.05).to(dev)
+    G = H // ps
+    P = G * G
+    cols = ops.patchify(pix, ps)
+    k = 3 * ps * ps
+    kpad = cols.shape[1]
+    wb = torch.zeros(C, kpad, dtype=torch.bfloat16, device=dev)
+    wb[:, :k] = w.reshape(C, k).bfloat16()
+    _, pe, _ = ops.gemm_nt(cols, wb, None, out_bf16=None, out_f32=True)
+    ref = F.conv2d(pix.bfloat16().double(), w.bfloat16().double(), stride=ps).flatten(2).transpose(1, 2)
+    assert _rel(pe, ref.reshape(B * P, C)) < 1e-5
+    cls = torch.randn(C, generator=g).to(dev)
+    pos = torch.randn(P + 1, C, generator=g).to(dev)
+    x = ops.vit_embed_fwd(pe, cls, pos, B, P)
+    xr = torch.cat([cls.expand(B, 1, C), pe.reshape(B, P, C)], 1) + pos
+    assert torch.allclose(x.reshape(B, P + 1, C), xr, atol=1e-6)
+    dx = torch.randn(B * (P + 1), C, generator=g).to(dev)
+    dpos = torch.empty(P + 1, C, device=dev)
+    dcls = torch.empty(C, device=dev)
+    dpatch = ops.vit_embed_bwd(dx, dpos, dcls, B, P)
+    d3 = dx.reshape(B, P + 1, C)
+    assert torch.allclose(dpos, d3.sum(0), atol=1e-5)
+    assert torch.allclose(dcls, d3[:, 0].sum(0), atol=1e-5)
+    assert torch.equal(dpatch, d3[:, 1:].reshape(B * P, C).bfloat16())
+
+
+def test_text_embedding_and_rows_copy(dev):
+    from lc2is_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(2)
+    V, C, B, L = 1000, 128, 3, 16
+    tok = torch.randn(V, C, generator=g).to(dev)
+    pos = torch.randn(77, C, generator=g).to(dev)
+    ids = torch.randint(0, V, (B, L), generator=g).to(dev)
+    x = ops.text_embed_fwd(ids, tok, pos)
+    assert torch.allclose(x.reshape(B, L, C), tok[ids] + pos[:L], atol=1e-6)
+    dx = torch.randn(B * L, C, generator=g).to(dev)
+    dtok = torch.zeros(V, C, device=dev)
+    dpos = torch.zeros(77, C, device=dev)
+    ops.text_embed_bwd(ids, dx, dtok, dpos)
+    rt = torch.zeros(V, C, device=dev).index_add_(0, ids.reshape(-1), dx)
+    assert torch.allclose(dtok, rt, atol=1e-5)
+    assert torch.allclose(dpos[:L], dx.reshape(B, L, C).sum(0), atol=1e-5)
+    src = torch.randn(B * 17, C, generator=g).to(dev)
+    d32 = torch.zeros(B * 16, C, device=dev)
+    d16 = torch.zeros(B * 16, C, dtype=torch.bfloat16, device=dev)
+    ops.rows_copy(src, 17, 1, 16, 0, B, 16, dst_f32=d32, dst_bf16=d16)
+    r = src.reshape(B, 17, C)[:, 1:].reshape(B * 16, C)
+    assert torch.equal(d32, r) and torch.equal(d16, r.bfloat16())
+    back = torch.zeros(B * 17, C, device=dev)
+    ops.rows_copy(d32, 16, 0, 17, 1, B, 16, dst_f32=back)
+    assert torch.equal(back.reshape(B, 17, C)[:, 1:], r.reshape(B, 16, C)) and back.reshape(B, 17, C)[:, 0].abs().sum() == 0
+
+
+def test_optimizers(dev):
+    from lc2is_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(3)
+    n = 4096 * 3
+    p0 = torch.randn(n, generator=g).to(dev)
+    for kind in ("sgd", "sgd_mom", "adamw"):
+        p = p0.clone()
+        pt = torch.nn.Parameter(p0.clone())
+        if kind == "sgd":
+            opt = torch.optim.SGD([pt], lr=0.1, weight_decay=0.01)
+            buf = None
+        elif kind == "sgd_mom":
+            opt = torch.optim.SGD([pt], lr=0.1, momentum=0.9, weight_decay=0.01)
+            buf = torch.zeros(n, device=dev)
+        else:
+            opt = torch.optim.AdamW([pt], lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)
+            m, v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        for step in range(1, 4):
+            gr = torch.randn(n, generator=g).to(dev)
+            pt.grad = gr.clone()
+            opt.step()
+            if kind == "adamw":
+                ops.adamw_step(p, gr, m, v, 1e-2, 0.9, 0.999, 1e-8, 0.05, step)
+            else:
+                ops.sgd_step(p, gr, buf, 0.1, 0.9 if buf is not None else 0.0, 0.01)
+        assert torch.allclose(p, pt.data, atol=2e-6, rtol=1e-5), kind
+
+
+@pytest.mark.parametrize("B,h,C,S,mode", [(2, 32, 151, 4, "bicubic"), (1, 8, 151, 4, "bicubic"),
+                                          (2, 8, 150, 16, "bilinear"), (1, 16, 37, 8, "bilinear"),
+                                          (1, 12, 151, 4, "bicubic")])
+def test_head_upsample_ce(dev, B, h, C, S, mode):
+    from lc2is_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(h + C)
+    ld = 192 if C > 128 else 64
+    lo = torch.zeros(B * h * h, ld)
+    lo[:, :C] = torch.randn(B * h * h, C, generator=g) * 3
+    lo = lo.to(dev)
+    H = h * S
+    labels = torch.randint(0, C, (B, H, H), generator=g).to(dev)
+    m = ops.INTERP_BICUBIC if mode == "bicubic" else ops.INTERP_BILINEAR
+    loss, dlo, hi = ops.head_upsample_ce(lo, labels, B, h, h, C, S, m, want_grad=True, want_scores=True,
+                                         grad_scale=1.0 / (B * H * H))
+    lod = lo[:, :C].double().reshape(B, h, h, C).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    up = F.interpolate(lod, scale_factor=S, mode=mode)
+    assert (hi.double() - up).abs().max().item() < 5e-5
+    ref_loss = F.cross_entropy(up, labels)
+    ref_loss.backward()
+    assert abs(loss[0].item() / loss[1].item() - ref_loss.item()) < 1e-4 * max(1.0, abs(ref_loss.item()))
+    assert int(loss[1].item()) == B * H * H
+    rg = lod.grad.permute(0, 2, 3, 1).reshape(B * h * h, C)
+    assert _rel(dlo[:, :C], rg) < 2e-5
+    assert dlo[:, C:].abs().sum().item() == 0
+    # ignore_index
+    labels2 = labels.clone()
+    labels2[:, ::3] = 0
+    loss2, dlo2, _ = ops.head_upsample_ce(lo, labels2, B, h, h, C, S, m, want_grad=True, ignore_index=0)
+    lod.grad = None
+    up2 = F.interpolate(lod, scale_factor=S, mode=mode)
+    rl2 = F.cross_entropy(up2, labels2, ignore_index=0, reduction="sum")
+    rl2.backward()
+    assert abs(loss2[0].item() - rl2.item()) < 1e-4 * abs(rl2.item())
+    assert int(loss2[1].item()) == int((labels2 != 0).sum().item())
+    assert _rel(dlo2[:, :C], lod.grad.permute(0, 2, 3, 1).reshape(B * h * h, C)) < 2e-5
+
+
+def test_ce_nchw(dev):
+    from lc2is_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(9)
+    B, C, H = 2, 151, 32
+    logits = (torch.randn(B, C, H, H, generator=g) * 2).to(dev)
+    labels = torch.randint(0, C, (B, H, H), generator=g).to(dev)
+    loss, lse = ops.ce_nchw_fwd(logits, labels)
+    ld = logits.double().requires_grad_(True)
+    ref = F.cross_entropy(ld, labels)
+    ref.backward()
+    assert abs(loss[0].item() / loss[1].item() - ref.item()) < 1e-5
+    d = ops.ce_nchw_bwd(logits, labels, lse, None, 1.0 / (B * H * H))
+    assert _rel(d, ld.grad) < 1e-5
