@@ -1,0 +1,375 @@
+"""CPU oracle for the LC2IS hot path — TEST INFRASTRUCTURE ONLY.
+
+A plain fp32 (or fp64) PyTorch restatement of what the reference computes on the path named by
+BASELINE.json:north_star.  Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this module; the product (``lc2is_amd``) never does.
+
+Pinning: the reference's own tests hold no golden vectors, so this restatement is pinned
+against outputs of the reference itself, produced in the build container by ``tools/make_golden.py``
+(which imports the reference's modules) and committed as tensors under ``tests/golden/``;
+``tests/test_oracle_golden.py`` checks every function here against them.
+
+Every function is written from explicit tensor algebra (matmul / softmax / mean / var / gather) — no
+``transformers`` import, no ``nn.Transformer*`` — and cites the reference lines it follows.  "hf:" =
+transformers/models/clip/modeling_clip.py (5.15.0), "torch:" = torch/nn (2.10).
+
+State dicts use the reference's own parameter names.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import torch
+
+Tensor = torch.Tensor
+
+
+# ----------------------------------------------------------------------------------------------------------
+# primitives
+# ----------------------------------------------------------------------------------------------------------
+def layer_norm(x: Tensor, w: Tensor, b: Tensor | None, eps: float = 1e-5) -> Tensor:
+    """torch:nn/functional.py layer_norm — biased variance over the last dim."""
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    y = (x - mu) / torch.sqrt(var + eps) * w
+    return y + b if b is not None else y
+
+
+def linear(x: Tensor, w: Tensor, b: Tensor | None = None) -> Tensor:
+    y = x @ w.transpose(-1, -2)
+    return y + b if b is not None else y
+
+
+def quick_gelu(x: Tensor) -> Tensor:
+    """hf:activations.py:122-123  x * sigmoid(1.702 x)."""
+    return x * torch.sigmoid(1.702 * x)
+
+
+def mha_core(q: Tensor, k: Tensor, v: Tensor, nhead: int, scale: float, bias: Tensor | None) -> Tensor:
+    """softmax(scale * Q K^T + bias) V per head.  q [B,Sq,C], k/v [B,Sk,C]; bias broadcastable to [B,H,Sq,Sk].
+    Follows hf:modeling_clip.py:259-277 (eager_attention_forward) and the attention core of
+    torch:nn/functional.py multi_head_attention_forward."""
+    B, Sq, C = q.shape
+    Sk = k.shape[1]
+    d = C // nhead
+    qh = q.reshape(B, Sq, nhead, d).transpose(1, 2)
+    kh = k.reshape(B, Sk, nhead, d).transpose(1, 2)
+    vh = v.reshape(B, Sk, nhead, d).transpose(1, 2)
+    s = (qh @ kh.transpose(-1, -2)) * scale
+    if bias is not None:
+        s = s + bias
+    p = torch.softmax(s, dim=-1)
+    return (p @ vh).transpose(1, 2).reshape(B, Sq, C)
+
+
+def _cubic_coeffs(t: Tensor, A: float = -0.75):
+    """torch upsample_bicubic2d cubic convolution coefficients (ATen UpSample.h get_cubic_upsample_coefficients)."""
+    def c1(x):
+        return ((A + 2) * x - (A + 3)) * x * x + 1
+
+    def c2(x):
+        return ((A * x - 5 * A) * x + 8 * A) * x - 4 * A
+
+    return c2(t + 1), c1(t), c1(1 - t), c2(2 - t)
+
+
+def interp_matrix(n_in: int, n_out: int, mode: str, scale: float | None = None, dtype=torch.float32) -> Tensor:
+    """U [n_out, n_in] with out = U @ in, for F.interpolate(align_corners=False) along one axis.
+    bicubic: A=-0.75, taps clamped to the border; bilinear: source index clamped at 0.
+    `scale` = 1/scale_factor when the caller passed scale_factor (model/model.py:43), else n_in/n_out (size=)."""
+    s = (n_in / n_out) if scale is None else scale
+    U = torch.zeros(n_out, n_in, dtype=torch.float64)
+    for o in range(n_out):
+        src = s * (o + 0.5) - 0.5
+        if mode == "bicubic":
+            i0 = math.floor(src)
+            t = src - i0
+            ws = _cubic_coeffs(torch.tensor(t, dtype=torch.float64))
+            for k in range(4):
+                idx = min(max(i0 - 1 + k, 0), n_in - 1)
+                U[o, idx] += float(ws[k])
+        elif mode == "bilinear":
+            src = max(src, 0.0)
+            i0 = int(src)
+            i1 = min(i0 + 1, n_in - 1)
+            l1 = src - i0
+            U[o, i0] += 1 - l1
+            U[o, i1] += l1
+        else:
+            raise ValueError(mode)
+    return U.to(dtype)
+
+
+def upsample2d(x: Tensor, scale_factor: int | None = None, size: int | None = None, mode: str = "bicubic") -> Tensor:
+    """x [B,C,h,w] -> [B,C,H,W]; separable, exactly F.interpolate(mode, align_corners=False)."""
+    h, w = x.shape[-2:]
+    if scale_factor is not None:
+        H, W, sc = h * scale_factor, w * scale_factor, 1.0 / scale_factor
+    else:
+        H = W = size
+        sc = None
+    Uy = interp_matrix(h, H, mode, sc, x.dtype)
+    Ux = interp_matrix(w, W, mode, sc if scale_factor is not None else None, x.dtype)
+    return Uy @ x @ Ux.transpose(0, 1)
+
+
+def cross_entropy(logits: Tensor, labels: Tensor, ignore_index: int = -100) -> Tensor:
+    """nn.CrossEntropyLoss() on [B,C,*] logits / [B,*] labels, mean over counted positions
+    (evaluate.py:68, engine.py:82,94,150)."""
+    C = logits.shape[1]
+    lg = logits.movedim(1, -1).reshape(-1, C)
+    lb = labels.reshape(-1)
+    lse = torch.logsumexp(lg, dim=-1)
+    keep = lb != ignore_index
+    picked = lg.gather(1, lb.clamp(0, C - 1).unsqueeze(1)).squeeze(1)
+    return ((lse - picked) * keep).sum() / keep.sum()
+
+
+# ----------------------------------------------------------------------------------------------------------
+# CLIP encoders (model/encoder.py -> hf CLIPVisionModel / CLIPTextModel)
+# ----------------------------------------------------------------------------------------------------------
+@dataclass
+class ClipCfg:
+    hidden: int
+    heads: int
+    layers: int
+    eps: float = 1e-5
+    patch: int = 16          # vision only
+    eos_token_id: int = 49407  # text only
+
+
+def _clip_layer(sd: dict, pre: str, x: Tensor, cfg: ClipCfg, bias: Tensor | None) -> Tensor:
+    """hf:modeling_clip.py:362-383 CLIPEncoderLayer.forward (pre-LN), attention :298-335, MLP :346-350."""
+    h = layer_norm(x, sd[pre + "layer_norm1.weight"], sd[pre + "layer_norm1.bias"], cfg.eps)
+    q = linear(h, sd[pre + "self_attn.q_proj.weight"], sd[pre + "self_attn.q_proj.bias"])
+    k = linear(h, sd[pre + "self_attn.k_proj.weight"], sd[pre + "self_attn.k_proj.bias"])
+    v = linear(h, sd[pre + "self_attn.v_proj.weight"], sd[pre + "self_attn.v_proj.bias"])
+    a = mha_core(q, k, v, cfg.heads, (cfg.hidden // cfg.heads) ** -0.5, bias)
+    x = x + linear(a, sd[pre + "self_attn.out_proj.weight"], sd[pre + "self_attn.out_proj.bias"])
+    h = layer_norm(x, sd[pre + "layer_norm2.weight"], sd[pre + "layer_norm2.bias"], cfg.eps)
+    h = quick_gelu(linear(h, sd[pre + "mlp.fc1.weight"], sd[pre + "mlp.fc1.bias"]))
+    return x + linear(h, sd[pre + "mlp.fc2.weight"], sd[pre + "mlp.fc2.bias"])
+
+
+def clip_vision_tokens(sd: dict, pre: str, pixel_values: Tensor, cfg: ClipCfg) -> Tensor:
+    """hf CLIPVisionModel.forward last_hidden_state (hf:613-656): conv patchify (no bias) + CLS + learned
+    positions (:202-218) -> pre_layrnorm -> layers; NO post_layernorm on tokens.  Returns [B, P+1, C]."""
+    w = sd[pre + "embeddings.patch_embedding.weight"]  # [C,3,p,p]
+    B, _, H, W = pixel_values.shape
+    p = cfg.patch
+    G = H // p
+    x = pixel_values[:, :, :G * p, :G * p].reshape(B, 3, G, p, G, p).permute(0, 2, 4, 1, 3, 5).reshape(B, G * G, 3 * p * p)
+    patches = x @ w.reshape(w.shape[0], -1).transpose(0, 1)
+    cls = sd[pre + "embeddings.class_embedding"].expand(B, 1, -1)
+    x = torch.cat([cls, patches], dim=1) + sd[pre + "embeddings.position_embedding.weight"]
+    x = layer_norm(x, sd[pre + "pre_layrnorm.weight"], sd[pre + "pre_layrnorm.bias"], cfg.eps)
+    for i in range(cfg.layers):
+        x = _clip_layer(sd, f"{pre}encoder.layers.{i}.", x, cfg, None)
+    return x
+
+
+def image_encoder_clip(sd: dict, pre: str, pixel_values: Tensor, cfg: ClipCfg) -> Tensor:
+    """ImageEncoderCLIP.forward: drop the CLS token (model/encoder.py:29-30)."""
+    return clip_vision_tokens(sd, pre + "enc.", pixel_values, cfg)[:, 1:, :]
+
+
+def image_encoder_clip_full(sd: dict, pre: str, pixel_values: Tensor, cfg: ClipCfg) -> Tensor:
+    """ImageEncoderCLIPFull.forward keeps CLS (model/encoder.py:67-68)."""
+    return clip_vision_tokens(sd, pre + "enc.", pixel_values, cfg)
+
+
+def pos_embedding_interpolate(pos: Tensor, tgt_size: int, patch: int = 16, pretrained: int = 224) -> Tensor:
+    """ImageEncoderCLIP.pos_emebedding_interpolate (model/encoder.py:32-44): bicubic resize (size=) of the
+    [1+g*g, C] table's grid part, CLS row kept."""
+    g = pretrained // patch
+    grid = pos[1:].reshape(g, g, -1).permute(2, 0, 1).unsqueeze(0)
+    new = upsample2d(grid, size=tgt_size, mode="bicubic")
+    new = new.squeeze(0).permute(1, 2, 0).reshape(tgt_size * tgt_size, -1)
+    return torch.cat([pos[:1], new], dim=0)
+
+
+def clip_text(sd: dict, pre: str, input_ids: Tensor, attention_mask: Tensor | None, cfg: ClipCfg):
+    """hf CLIPTextModel.forward (hf:513-586): token+position embedding, causal ∧ padding additive mask,
+    pre-LN layers, final_layer_norm; pooled = state at the first EOS position (:572-581)."""
+    B, L = input_ids.shape
+    x = sd[pre + "embeddings.token_embedding.weight"][input_ids] + sd[pre + "embeddings.position_embedding.weight"][:L]
+    neg = torch.finfo(x.dtype).min
+    bias = torch.zeros(B, 1, L, L, dtype=x.dtype)
+    bias = bias.masked_fill(torch.ones(L, L, dtype=torch.bool).triu(1), neg)
+    if attention_mask is not None:
+        bias = bias.masked_fill((attention_mask == 0)[:, None, None, :], neg)
+    for i in range(cfg.layers):
+        x = _clip_layer(sd, f"{pre}encoder.layers.{i}.", x, cfg, bias)
+    x = layer_norm(x, sd[pre + "final_layer_norm.weight"], sd[pre + "final_layer_norm.bias"], cfg.eps)
+    eos = (input_ids == cfg.eos_token_id).int().argmax(dim=-1)
+    return x, x[torch.arange(B), eos]
+
+
+def text_encoder_clip(sd, pre, input_ids, attention_mask, cfg) -> Tensor:
+    """TextEncoderCLIP.forward (model/encoder.py:98-99)."""
+    return clip_text(sd, pre + "enc.", input_ids, attention_mask, cfg)[0]
+
+
+def text_encoder_clip_pooler(sd, pre, input_ids, attention_mask, cfg) -> Tensor:
+    """TextEncoderCLIPPooler.forward (model/encoder.py:115-116)."""
+    return clip_text(sd, pre + "enc.", input_ids, attention_mask, cfg)[1]
+
+
+# ----------------------------------------------------------------------------------------------------------
+# decoder (model/decoder.py:9-21 -> torch TransformerDecoderLayer / MultiheadAttention)
+# ----------------------------------------------------------------------------------------------------------
+def decoder_layer(sd: dict, pre: str, tgt: Tensor, memory: Tensor, nhead: int, norm_first: bool = True,
+                  memory_key_padding_mask: Tensor | None = None, eps: float = 1e-5) -> Tensor:
+    """DecoderLayer.forward = torch:nn/modules/transformer.py:1131-1145 with multihead_attn rebuilt for
+    kdim=vdim=d_kv (separate q/k/v projection weights, packed in_proj_bias).  Biases are optional: under
+    torch 2.10 the reference creates self_attn / linear1-2 / norm1-3 without them (SURVEY.md §2 drift #1)."""
+    g = lambda k: sd.get(pre + k)  # noqa: E731
+    C = tgt.shape[-1]
+    scale = (C // nhead) ** -0.5
+
+    def sa(x):
+        w, b = g("self_attn.in_proj_weight"), g("self_attn.in_proj_bias")
+        qkv = linear(x, w, b)
+        q, k, v = qkv.split(C, dim=-1)
+        a = mha_core(q, k, v, nhead, scale, None)
+        return linear(a, g("self_attn.out_proj.weight"), g("self_attn.out_proj.bias"))
+
+    def ca(x):
+        b = g("multihead_attn.in_proj_bias")
+        bq, bk, bv = (b.split(C) if b is not None else (None, None, None))
+        q = linear(x, g("multihead_attn.q_proj_weight"), bq)
+        k = linear(memory, g("multihead_attn.k_proj_weight"), bk)
+        v = linear(memory, g("multihead_attn.v_proj_weight"), bv)
+        bias = None
+        if memory_key_padding_mask is not None:
+            bias = torch.zeros(memory.shape[0], 1, 1, memory.shape[1], dtype=x.dtype)
+            bias = bias.masked_fill(memory_key_padding_mask[:, None, None, :], float("-inf"))
+        a = mha_core(q, k, v, nhead, scale, bias)
+        return linear(a, g("multihead_attn.out_proj.weight"), g("multihead_attn.out_proj.bias"))
+
+    def ff(x):
+        return linear(torch.relu(linear(x, g("linear1.weight"), g("linear1.bias"))), g("linear2.weight"),
+                      g("linear2.bias"))
+
+    n = lambda i, x: layer_norm(x, g(f"norm{i}.weight"), g(f"norm{i}.bias"), eps)  # noqa: E731
+    x = tgt
+    if norm_first:
+        x = x + sa(n(1, x))
+        x = x + ca(n(2, x))
+        x = x + ff(n(3, x))
+    else:
+        x = n(1, x + sa(x))
+        x = n(2, x + ca(x))
+        x = n(3, x + ff(x))
+    return x
+
+
+def decoder_block(sd, pre, tgt, memory, nhead, num_layers, norm_first=True, memory_key_padding_mask=None):
+    """DecoderBlock.forward (model/decoder.py:20-21): num_layers layers, no final norm."""
+    x = tgt
+    for i in range(num_layers):
+        x = decoder_layer(sd, f"{pre}layers.{i}.", x, memory, nhead, norm_first, memory_key_padding_mask)
+    return x
+
+
+def text_to_patch(sd, pre, img: Tensor, text: Tensor):
+    """TextToPatch.forward (model/text_patch.py:14-19) — returns (t_feature, v_feature), text first."""
+    return (linear(text, sd[pre + "textual.weight"], sd[pre + "textual.bias"]),
+            linear(img, sd[pre + "visual.weight"], sd[pre + "visual.bias"]))
+
+
+# ----------------------------------------------------------------------------------------------------------
+# composition (model/model.py:27-56) and the training step (engine.py:69-123)
+# ----------------------------------------------------------------------------------------------------------
+@dataclass
+class BaseCfg:
+    in_size: int
+    out_size: int
+    patch: int
+    vision: ClipCfg
+    text: ClipCfg
+    dec_heads: int = 8
+    dec_layers: int = 1
+
+
+def base_model_with_text(sd: dict, inputs: dict, cfg: BaseCfg):
+    """BaseModelWithText.forward, literal operation order (model/model.py:27-56).
+    Returns (feature_t [K,512], feature_v [B,out²,512], logits [B,K,out,out])."""
+    enc_t = text_encoder_clip(sd, "text_encoder.", inputs["input_ids"], inputs["attention_mask"], cfg.text)
+    enc_v = image_encoder_clip(sd, "vision_encoder.", inputs["pixel_values"], cfg.vision)
+    kpm = inputs["attention_mask"] != 1
+    dec_v = decoder_block(sd, "vision_decoder.", enc_v, enc_t, cfg.dec_heads, cfg.dec_layers, True, kpm)
+    B, P, C = dec_v.shape
+    H = cfg.in_size // cfg.patch
+    x = dec_v.reshape(B, H, H, C).permute(0, 3, 1, 2)
+    x = upsample2d(x, scale_factor=4, mode="bicubic")
+    x = x.permute(0, 2, 3, 1).reshape(B, cfg.out_size * cfg.out_size, C)
+    feature_t, feature_v = text_to_patch(sd, "pixel_patch.", x, sd["class_prototypes"])
+    mm = feature_v @ feature_t.transpose(1, 0)
+    logits = mm.reshape(B, cfg.out_size, cfg.out_size, -1).permute(0, 3, 1, 2)
+    return feature_t, feature_v, logits
+
+
+def train_step_sgd(sd: dict, inputs: dict, labels: Tensor, cfg: BaseCfg, lr: float):
+    """One iteration of Engine.train_loop (engine.py:78-104) without aux loss: zero_grad -> forward -> CE
+    (mean) -> backward -> SGD step.  Returns (loss, logits, grads dict, new params dict)."""
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point()}
+    full = dict(sd)
+    full.update(params)
+    _, _, logits = base_model_with_text(full, inputs, cfg)
+    loss = cross_entropy(logits, labels)
+    loss.backward()
+    grads = {k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in params.items()}
+    new = {k: (p.detach() - lr * grads[k]) for k, p in params.items()}
+    return loss.detach(), logits.detach(), grads, new
+
+
+# ----------------------------------------------------------------------------------------------------------
+# losses (model/loss.py) and the parity metric (metrics.py:82-102)
+# ----------------------------------------------------------------------------------------------------------
+def auxiliary_loss(inp: Tensor, target: Tensor, ignore_index: int = -100) -> Tensor:
+    """AuxiliaryLoss.forward (model/loss.py:17-21): bilinear resize to the label size (size=H), then CE."""
+    H = target.shape[1]
+    return cross_entropy(upsample2d(inp, size=H, mode="bilinear"), target, ignore_index)
+
+
+def npair_loss(x: Tensor, x_pos: Tensor, x_neg: Tensor) -> Tensor:
+    """NPairLoss.forward (model/loss.py:30-37) with the default mean reduction."""
+    pos = x @ x_pos.transpose(0, 1)
+    neg = (x @ x_neg.transpose(0, 1)).sum(-1, keepdim=True)
+    return (pos / (pos + neg)).sum(-1).mean()
+
+
+def contrastive_loss(outputs: Tensor, labels: Tensor, num_classes: int = 151):
+    """ContrastiveLoss.forward (model/loss.py:46-64).  outputs [B,HW,K]; labels [B,H,W].
+    loss_visual: CE over classes per pixel; loss_textual: CE over dim 1 (=H!) of the [B,H,W,K] view against
+    one-hot float targets — the reference passes the class axis LAST, so torch softmaxes over dim 1."""
+    B, HW, K = outputs.shape
+    H = int(math.sqrt(HW))
+    out_textual = outputs.reshape(B, H, H, K)
+    out_visual = outputs.transpose(-2, -1).reshape(B, K, H, H)
+    onehot = torch.nn.functional.one_hot(labels, num_classes).to(outputs.dtype)  # [B,H,W,K]
+    logp = torch.log_softmax(out_textual, dim=1)
+    loss_textual = -(onehot * logp).sum(dim=1).mean()
+    loss_visual = cross_entropy(out_visual, labels)
+    return (loss_textual + loss_visual) / 2, loss_visual, loss_textual
+
+
+def compute_miou(outputs: Tensor, labels: Tensor, n_class: int = 151, ignore_index: int = 0) -> float:
+    """metrics.compute_mIOU (metrics.py:82-102) without torchmetrics: per image, bicubic x4 of the logits and
+    nearest x4 of the labels, argmax (Softmax2d is monotone), per-class IoU (JaccardIndex average="none"),
+    mean over the classes present in the label excluding ignore_index; mean over images."""
+    vals = []
+    for i in range(outputs.shape[0]):
+        up = upsample2d(outputs[i:i + 1], scale_factor=4, mode="bicubic")[0]
+        lab = labels[i].repeat_interleave(4, 0).repeat_interleave(4, 1)
+        pred = up.argmax(0)
+        present = [c for c in torch.unique(lab).tolist() if c != ignore_index]
+        ious = []
+        for c in present:
+            inter = ((pred == c) & (lab == c)).sum().item()
+            union = ((pred == c) | (lab == c)).sum().item()
+            ious.append(inter / union if union else 0.0)
+        vals.append(sum(ious) / len(ious) if ious else float("nan"))
+    return float(sum(vals) / len(vals))

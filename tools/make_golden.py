@@ -1,0 +1,213 @@
+"""Generate tests/golden/*.pt by running the REFERENCE's own modules (imported from /root/reference) on
+seeded inputs, in the build container (CPU).  Fixtures are tensors only (loadable with weights_only=True):
+weights, inputs, and the reference's outputs / losses / gradients / post-SGD parameters.
+
+Hub-named constructors cannot run offline, so the reference wrappers are created without
+their ``__init__`` and given config-built, seeded transformers models; every ``forward`` executed below is
+the reference's own, unchanged.
+
+Usage:  python tools/make_golden.py            (needs /root/reference; never runs on the GPU box)
+"""
+from __future__ import annotations
+
+import sys
+from pathlib import Path
+
+sys.dont_write_bytecode = True
+REF = Path("/root/reference")
+ROOT = Path(__file__).resolve().parent.parent
+OUT = ROOT / "tests" / "golden"
+
+import torch  # noqa: E402
+from torch import nn  # noqa: E402
+
+
+def _ref_imports():
+    sys.path.insert(0, str(REF))
+    from transformers import CLIPTextConfig, CLIPTextModel, CLIPVisionConfig, CLIPVisionModel  # noqa
+    import model.decoder as rdec  # noqa
+    import model.encoder as renc  # noqa
+    import model.loss as rloss  # noqa
+    import model.model as rmodel  # noqa
+    import model.text_patch as rtp  # noqa
+    return dict(CLIPTextConfig=CLIPTextConfig, CLIPTextModel=CLIPTextModel, CLIPVisionConfig=CLIPVisionConfig,
+                CLIPVisionModel=CLIPVisionModel, rdec=rdec, renc=renc, rloss=rloss, rmodel=rmodel, rtp=rtp)
+
+
+def _bare(cls):
+    obj = object.__new__(cls)
+    nn.Module.__init__(obj)
+    return obj
+
+
+def make_base_tiny(R):
+    """BaseModelWithText (model/model.py:12-56) at HIP-compatible tiny dims + one SGD training step."""
+    torch.manual_seed(1024)  # evaluate.py:24 default seed
+    vcfg = R["CLIPVisionConfig"](hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                                 image_size=64, patch_size=16)
+    tcfg = R["CLIPTextConfig"](vocab_size=512, hidden_size=64, intermediate_size=128, num_hidden_layers=2,
+                               num_attention_heads=1, max_position_embeddings=77, eos_token_id=511, bos_token_id=510,
+                               pad_token_id=511)
+    m = _bare(R["rmodel"].BaseModelWithText)
+    m.patch_size, m.in_size, m.out_size = 16, 64, 16
+    m.vision_encoder = _bare(R["renc"].ImageEncoderCLIP)
+    m.vision_encoder.in_size, m.vision_encoder.patch_size = 64, 16
+    m.vision_encoder.enc = R["CLIPVisionModel"](vcfg)
+    m.text_encoder = _bare(R["renc"].TextEncoderCLIP)
+    m.text_encoder.patch_size = 16
+    m.text_encoder.enc = R["CLIPTextModel"](tcfg)
+    protos = torch.load(REF / "model" / "ade20k_prototypes.pt", weights_only=True)
+    m.class_prototypes = nn.Parameter(protos.clone(), requires_grad=True)
+    layer = R["rdec"].DecoderLayer(d_model=128, d_kv=64, nhead=2, dim_feedforward=128, dropout=0, batch_first=True,
+                                   norm_first=True)
+    m.vision_decoder = R["rdec"].DecoderBlock(decoder_layer=layer, num_layers=1)
+    m.pixel_patch = R["rtp"].TextToPatch(out=64, img_in=128, text_in=512)
+    m.train()
+
+    g = torch.Generator().manual_seed(7)
+    B, L = 2, 8
+    pixel_values = torch.randn(B, 3, 64, 64, generator=g)
+    input_ids = torch.randint(1, 509, (B, L), generator=g)
+    input_ids[:, 0] = 510
+    input_ids[0, 5] = 511
+    input_ids[0, 6:] = 511
+    input_ids[1, 7] = 511
+    attention_mask = torch.ones(B, L, dtype=torch.int64)
+    attention_mask[0, 6:] = 0
+    labels = torch.randint(0, 151, (B, 16, 16), generator=g)
+    inputs = dict(pixel_values=pixel_values, input_ids=input_ids, attention_mask=attention_mask)
+
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    feature_t, feature_v, logits = m(inputs)
+    loss = nn.CrossEntropyLoss()(logits, labels)
+    opt = torch.optim.SGD(m.parameters(), lr=0.05)
+    opt.zero_grad()
+    loss.backward()
+    grads = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+    opt.step()
+    sd1 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    # keep the fixture small: all grads as per-tensor (sum, abs-sum, first 8 values) + a few full tensors
+    keep_full = ["class_prototypes", "pixel_patch.visual.weight", "vision_decoder.layers.0.multihead_attn.k_proj_weight",
+                 "vision_encoder.enc.encoder.layers.0.self_attn.q_proj.weight",
+                 "vision_encoder.enc.embeddings.position_embedding.weight",
+                 "text_encoder.enc.encoder.layers.1.mlp.fc1.weight", "vision_encoder.enc.pre_layrnorm.bias"]
+    fx = dict(
+        state_dict=sd0, pixel_values=pixel_values, input_ids=input_ids, attention_mask=attention_mask, labels=labels,
+        feature_t=feature_t.detach(), feature_v=feature_v.detach(), logits=logits.detach(), loss=loss.detach(),
+        grad_stats={k: torch.stack([v.sum(), v.abs().sum()]) for k, v in grads.items()},
+        grad_full={k: grads[k] for k in keep_full},
+        after_step={k: sd1[k] for k in keep_full}, lr=torch.tensor(0.05),
+    )
+    torch.save(fx, OUT / "base_tiny.pt")
+    print("base_tiny: loss", float(loss), "logits", tuple(logits.shape), "n_grads", len(grads))
+
+
+def make_decoder_d96(R):
+    """DecoderBlock/DecoderLayer (model/decoder.py:9-21) with head_dim 96, key padding mask, 2 layers."""
+    torch.manual_seed(11)
+    layer = R["rdec"].DecoderLayer(d_model=192, d_kv=128, nhead=2, dim_feedforward=128, dropout=0, batch_first=True,
+                                   norm_first=True)
+    blk = R["rdec"].DecoderBlock(decoder_layer=layer, num_layers=2)
+    for p in blk.parameters():  # _get_clones deep-copies: make the two layers differ
+        with torch.no_grad():
+            p.add_(0.02 * torch.randn_like(p))
+    g = torch.Generator().manual_seed(12)
+    tgt = torch.randn(2, 16, 192, generator=g, requires_grad=True)
+    mem = torch.randn(2, 7, 128, generator=g, requires_grad=True)
+    kpm = torch.zeros(2, 7, dtype=torch.bool)
+    kpm[0, 4:] = True
+    out = blk(tgt=tgt, memory=mem, memory_key_padding_mask=kpm)
+    dout = torch.randn(out.shape, generator=g)
+    out.backward(dout)
+    fx = dict(state_dict={k: v.detach().clone() for k, v in blk.state_dict().items()}, tgt=tgt.detach(),
+              memory=mem.detach(), kpm=kpm, out=out.detach(), dout=dout, dtgt=tgt.grad.clone(), dmem=mem.grad.clone(),
+              grads={k: p.grad.clone() for k, p in blk.named_parameters()})
+    torch.save(fx, OUT / "decoder_d96.pt")
+    print("decoder_d96: out", tuple(out.shape), "keys", len(fx["state_dict"]))
+
+
+def make_ops(R):
+    """Per-op vectors: interpolation, losses, pooled text output, pos-embedding resize."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(21)
+    fx = {}
+    x = torch.randn(2, 5, 6, 6, generator=g)
+    fx["interp_in"] = x
+    fx["bicubic_x4"] = F.interpolate(x, mode="bicubic", scale_factor=4)
+    fx["bilinear_x2"] = F.interpolate(x, mode="bilinear", scale_factor=2)
+    fx["bilinear_x4"] = F.interpolate(x, mode="bilinear", scale_factor=4)
+    fx["bilinear_size20"] = F.interpolate(x, mode="bilinear", size=20)
+    fx["bicubic_size9"] = F.interpolate(x, mode="bicubic", size=9)
+    # losses (model/loss.py)
+    logits = torch.randn(2, 151, 8, 8, generator=g)
+    labels = torch.randint(0, 151, (2, 8, 8), generator=g)
+    fx["ce_logits"], fx["ce_labels"] = logits, labels
+    fx["ce"] = nn.CrossEntropyLoss()(logits, labels)
+    low = torch.randn(2, 151, 4, 4, generator=g)
+    lab16 = torch.randint(0, 151, (2, 16, 16), generator=g)
+    fx["aux_in"], fx["aux_labels"] = low, lab16
+    fx["aux"] = R["rloss"].AuxiliaryLoss()(low, lab16)
+    outs = torch.randn(2, 64, 151, generator=g)
+    fx["con_in"] = outs
+    c = R["rloss"].ContrastiveLoss()(outs, labels)
+    fx["con"] = torch.stack([c[0], c[1], c[2]])
+    a, p, n = torch.randn(6, 16, generator=g), torch.randn(3, 16, generator=g), torch.randn(5, 16, generator=g)
+    fx["np_x"], fx["np_pos"], fx["np_neg"] = a, p, n
+    fx["npair"] = R["rloss"].NPairLoss()(a, p, n)
+    # pooled text (TextEncoderCLIPPooler, model/encoder.py:104-116)
+    torch.manual_seed(5)
+    tcfg = R["CLIPTextConfig"](vocab_size=300, hidden_size=64, intermediate_size=128, num_hidden_layers=1,
+                               num_attention_heads=1, max_position_embeddings=77, eos_token_id=299, bos_token_id=298,
+                               pad_token_id=299)
+    te = _bare(R["renc"].TextEncoderCLIPPooler)
+    te.patch_size = 16
+    te.enc = R["CLIPTextModel"](tcfg)
+    te.eval()
+    ids = torch.randint(1, 297, (3, 9), generator=g)
+    ids[:, 0] = 298
+    ids[0, 4] = 299
+    ids[1, 8] = 299
+    ids[2, 2] = 299
+    mask = torch.ones(3, 9, dtype=torch.int64)
+    mask[0, 5:] = 0
+    mask[2, 3:] = 0
+    with torch.no_grad():
+        fx["pool_sd"] = {k: v.clone() for k, v in te.state_dict().items()}
+        fx["pool_ids"], fx["pool_mask"] = ids, mask
+        fx["pool_out"] = te(input_ids=ids, attention_mask=mask)
+    # pos-embedding resize (ImageEncoderCLIP.pos_emebedding_interpolate, model/encoder.py:32-44), 14x14 -> 8x8
+    torch.manual_seed(6)
+    vcfg = R["CLIPVisionConfig"](hidden_size=32, intermediate_size=64, num_hidden_layers=1, num_attention_heads=1,
+                                 image_size=224, patch_size=16)
+    ve = _bare(R["renc"].ImageEncoderCLIP)
+    ve.in_size, ve.patch_size = 128, 16
+    inner = R["CLIPVisionModel"](vcfg)
+
+    class _Legacy(nn.Module):  # the reference addresses `enc.vision_model.embeddings` (pre-5.x layout)
+        def __init__(self, vm):
+            super().__init__()
+            self.vision_model = vm
+
+    ve.enc = _Legacy(inner)
+    with torch.no_grad():
+        fx["posint_in"] = inner.embeddings.position_embedding.weight.detach().clone()
+        fx["posint_out"] = ve.pos_emebedding_interpolate(tgt_size=8).detach().clone()
+    torch.save(fx, OUT / "ops.pt")
+    print("ops:", sorted(fx.keys()))
+
+
+def main():
+    OUT.mkdir(parents=True, exist_ok=True)
+    R = _ref_imports()
+    make_base_tiny(R)
+    make_decoder_d96(R)
+    make_ops(R)
+    # the reference's only data fixture on this path — copied as-is
+    protos = torch.load(REF / "model" / "ade20k_prototypes.pt", weights_only=True)
+    torch.save(protos.clone(), OUT / "ade20k_prototypes.pt")
+    for f in sorted(OUT.glob("*.pt")):
+        print(f.name, f.stat().st_size // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()
