@@ -41,7 +41,7 @@ typedef struct {
   void* dstT;      /* bf16 [K, ld_dstT] transposed copy (dgrad GEMM operand), may be NULL  */
   int N, K, ld_dst, ld_dstT;
   int tile_start;  /* exclusive prefix sum of ceil(N/64)*ceil(K/64) over the table          */
-  int reserved;
+  int flags;       /* bit 0: dst is fp32 and receives a plain copy (fused bias vectors); dstT unused     */
 } lc2is_shadow_desc;
 
 /* ABI / build identification: returns a static string "lc2is_hip <abi> gfx950". Host memory. */
@@ -169,6 +169,10 @@ int lc2is_adamw_step(float* params, const float* grads, float* exp_avg, float* e
 int lc2is_head_upsample_ce(const float* scores_lo, int ld, const int64_t* labels, float* dscores_lo,
                            float* scores_hi, float* loss_sum, int B, int h, int w, int C, int S, int mode,
                            long ignore_index, float grad_scale, lc2is_stream_t stream);
+/* Transposed upsample (autograd of F.interpolate) for the unfused path: dhi NCHW fp32 [B,C,h*S,w*S] ->
+ * dlo channels-last fp32 [B,h,w,ld] (columns >= C untouched). */
+int lc2is_upsample_bwd_nchw(const float* dhi, float* dlo, int ld, int B, int h, int w, int C, int S, int mode,
+                            lc2is_stream_t stream);
 /* Plain nn.CrossEntropyLoss on NCHW fp32 logits (the unfused drop-in path): forward saves per-pixel lse,
  * backward writes dlogits = grad_scale * (*grad_scale_dev) * (softmax - onehot). */
 int lc2is_ce_nchw_fwd(const float* logits, const int64_t* labels, float* lse, float* loss_sum, int B, int C,

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_ce_kernel(HeadArgs p) {
   const int Yl = Y0 + py_l, Xl = X0 + px_l;
   int my_label = -1;
   const bool my_valid = (Yl < p.H && Xl < p.W);
-  if (my_valid) {
+  if (my_valid && p.labels) {
     const int64_t lab64 = p.labels[((size_t)b * p.H + Yl) * p.W + Xl];
     my_label = (lab64 == (int64_t)p.ignore_index || lab64 < 0 || lab64 >= p.C) ? -1 : (int)lab64;
   }
@@ -254,7 +254,56 @@ __global__ __launch_bounds__(256) void ce_nchw_bwd_kernel(const float* __restric
   }
 }
 
+// Transposed upsample for the unfused path: dlo[b,y,x,c] = sum_{Y,X} wy(Y,y) wx(X,x) dhi[b,c,Y,X].
+// grid (h, C, B), threads over x; each thread scans the <= 5S x 5S window of output pixels that can touch it.
+template <int MODE>
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ dhi, float* dlo, int ld,
+                                                            int h, int w, int C, int S) {
+  const int y = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
+  const int H = h * S, W = w * S;
+  const float inv_scale = 1.f / (float)S;
+  const float* plane = dhi + ((size_t)b * C + c) * H * W;
+  for (int x = threadIdx.x; x < w; x += 256) {
+    float acc = 0.f;
+    const int Y0 = max(0, S * (y - 2)), Y1 = min(H, S * (y + 3));
+    const int X0 = max(0, S * (x - 2)), X1 = min(W, S * (x + 3));
+    for (int Y = Y0; Y < Y1; ++Y) {
+      const Taps ty = make_taps(Y, inv_scale, h, MODE);
+      float wy = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) wy += (ty.idx[k] == y) ? ty.w[k] : 0.f;
+      if (wy == 0.f) continue;
+      float racc = 0.f;
+      for (int X = X0; X < X1; ++X) {
+        const Taps tx = make_taps(X, inv_scale, w, MODE);
+        float wx = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wx += (tx.idx[k] == x) ? tx.w[k] : 0.f;
+        racc += wx * plane[(size_t)Y * W + X];
+      }
+      acc += wy * racc;
+    }
+    dlo[(((size_t)b * h + y) * w + x) * ld + c] = acc;
+  }
+}
+
 }  // namespace
+
+extern "C" int lc2is_upsample_bwd_nchw(const float* dhi, float* dlo, int ld, int B, int h, int w, int C, int S,
+                                       int mode, lc2is_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!dhi || !dlo) return LC2IS_ERR_NULL;
+  if (B <= 0 || h <= 0 || w <= 0 || C <= 0 || ld < C || S < 1) return LC2IS_ERR_SHAPE;
+  if (mode == LC2IS_INTERP_BICUBIC)
+    hipLaunchKernelGGL(upsample_bwd_kernel<LC2IS_INTERP_BICUBIC>, dim3(h, C, B), dim3(256), 0, stream, dhi, dlo,
+                       ld, h, w, C, S);
+  else if (mode == LC2IS_INTERP_BILINEAR)
+    hipLaunchKernelGGL(upsample_bwd_kernel<LC2IS_INTERP_BILINEAR>, dim3(h, C, B), dim3(256), 0, stream, dhi, dlo,
+                       ld, h, w, C, S);
+  else
+    return LC2IS_ERR_UNSUPPORTED;
+  return lc2is_check_launch();
+}
 
 extern "C" int lc2is_head_upsample_ce(const float* scores_lo, int ld, const int64_t* labels, float* dscores_lo,
                                       float* scores_hi, float* loss_sum, int B, int h, int w, int C, int S,

@@ -38,7 +38,9 @@ __global__ __launch_bounds__(256) void shadow_refresh_kernel(const lc2is_shadow_
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (n < d.N && k < d.K) v = *reinterpret_cast<const float4*>(src + (size_t)n * d.K + k);  // K % 4 == 0
     const bf16_t b0 = f32_to_bf16(v.x), b1 = f32_to_bf16(v.y), b2 = f32_to_bf16(v.z), b3 = f32_to_bf16(v.w);
-    if (dst && n < d.N && k < d.K) {
+    if (d.flags & 1) {  // plain fp32 copy (fused bias vectors)
+      if (dst && n < d.N && k < d.K) *reinterpret_cast<float4*>((float*)d.dst + (size_t)n * d.ld_dst + k) = v;
+    } else if (dst && n < d.N && k < d.K) {
       uint2 pk = make_uint2((unsigned)b0 | ((unsigned)b1 << 16), (unsigned)b2 | ((unsigned)b3 << 16));
       *reinterpret_cast<uint2*>(dst + (size_t)n * d.ld_dst + k) = pk;
     }

@@ -1,0 +1,11 @@
+"""Drop-in ``nn.Module`` replacements for the reference's hot-path modules."""
+from .base import HipModule, ParamArena
+from .clip import (ClipArch, ImageEncoderCLIP, ImageEncoderCLIPFull, TextEncoderCLIP, TextEncoderCLIPPooler,
+                   TEXT_B, TEXT_L, VIT_B16, VIT_L14)
+from .decoder import DecoderBlock, DecoderLayer
+from .loss import AuxiliaryLoss, CrossEntropyLoss
+from .model import BaseModelWithText, TextToPatch
+
+__all__ = ["HipModule", "ParamArena", "ClipArch", "ImageEncoderCLIP", "ImageEncoderCLIPFull", "TextEncoderCLIP",
+           "TextEncoderCLIPPooler", "DecoderBlock", "DecoderLayer", "AuxiliaryLoss", "CrossEntropyLoss",
+           "BaseModelWithText", "TextToPatch", "VIT_B16", "VIT_L14", "TEXT_B", "TEXT_L"]

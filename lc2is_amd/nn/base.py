@@ -1,0 +1,168 @@
+"""Shared machinery of the drop-in modules: bf16 weight shadows, gradient buffers, the flat arena.
+
+Design (MI355X-first):
+  * parameters stay fp32 ``nn.Parameter``s under the reference's names (``state_dict`` interchange);
+  * every GEMM weight has two bf16 *shadows* in HBM — row-major [N,K] for the forward product and the
+    transposed [K,N] for the dgrad product (so both are NT MFMA GEMMs) — refreshed for the whole module by
+    ONE kernel launch whenever a parameter's version counter moved (optimizer step, ``load_state_dict``);
+  * gradients are written by the HIP backward kernels straight into per-parameter buffers (views of one
+    flat arena when ``ParamArena`` is used), never returned through autograd;
+  * the module-level ``torch.autograd.Function``s only tie the modules together.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from .. import ops
+
+
+def require_cuda(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"lc2is_amd: {what} is on {t.device}; the MI355X path has no CPU fallback — move the module and its "
+            "inputs to a HIP device (the CPU oracle lives in oracle/ and is test-only)")
+
+
+class HipModule(nn.Module):
+    """Base of the top-level drop-in modules (one shadow table per instance)."""
+
+    def __init__(self) -> None:
+        super().__init__()
+        self._sh = None           # namespace of shadow tensors
+        self._sh_table = None
+        self._sh_versions = None
+        self._sh_device = None
+        self._sh_ptrs = []
+
+    # subclasses: return (namespace_dict, entries) where entries = [(param, dst, dstT)]
+    def _build_shadows(self, device):  # pragma: no cover - abstract
+        raise NotImplementedError
+
+    def _params_for_version(self):
+        return list(self.parameters(recurse=True))
+
+    def _ensure_ready(self):
+        ps = self._params_for_version()
+        dev = ps[0].device
+        require_cuda(ps[0], f"{type(self).__name__} parameters")
+        if self._sh is None or self._sh_device != dev or any(p.data_ptr() != q for p, q in zip(ps, self._sh_ptrs)):
+            ns, entries = self._build_shadows(dev)
+            self._sh = ns
+            self._sh_table = ops.ShadowTable(entries, dev) if entries else None
+            self._sh_device = dev
+            self._sh_ptrs = [p.data_ptr() for p in ps]
+            self._sh_versions = None
+        vers = [p._version for p in ps]
+        if vers != self._sh_versions:
+            if self._sh_table is not None:
+                self._sh_table.refresh()
+            self._post_refresh()
+            self._sh_versions = vers
+        return self._sh
+
+    def _post_refresh(self):
+        pass
+
+    def invalidate_shadows(self):
+        """Call after changing parameters behind torch's back (the fused optimizer kernels do)."""
+        self._sh_versions = None
+
+    def _apply(self, fn, *args, **kwargs):  # .to()/.cuda() invalidate the shadows
+        self._sh = None
+        return super()._apply(fn, *args, **kwargs)
+
+
+def grad_buf(p: torch.Tensor):
+    """(buffer, accumulate) for writing the gradient of parameter ``p`` from a HIP kernel."""
+    if p.grad is None:
+        g = getattr(p, "_lc2is_grad", None)
+        if g is None or g.shape != p.shape or g.device != p.device:
+            g = torch.empty_like(p)
+        p.grad = g
+        return g, False
+    return p.grad, True
+
+
+def linear_bwd_params(dy_bf16: torch.Tensor, x_bf16: torch.Tensor, weight: nn.Parameter, bias: nn.Parameter | None):
+    """dW = dy^T x, db = colsum(dy), written into the parameters' gradient buffers."""
+    if weight.requires_grad:
+        g, acc = grad_buf(weight)
+        ops.gemm_tn(dy_bf16, x_bf16, g.reshape(g.shape[0], -1), accumulate=acc)
+    if bias is not None and bias.requires_grad:
+        g, acc = grad_buf(bias)
+        ops.colsum(dy_bf16, g, accumulate=acc)
+
+
+def vec_grad(p: nn.Parameter | None):
+    if p is None or not p.requires_grad:
+        return None, False
+    return grad_buf(p)
+
+
+class ParamArena:
+    """Flat fp32 storage for all parameters (and their gradients) of a model: one fused optimizer launch,
+    one contiguous all-reduce payload, 256-byte aligned views.  Build AFTER moving the model to the GPU."""
+
+    ALIGN = 64  # elements
+
+    def __init__(self, module: nn.Module):
+        params = []
+        seen = set()
+        for p in module.parameters():
+            if id(p) not in seen:
+                seen.add(id(p))
+                params.append(p)
+        if not params:
+            raise RuntimeError("ParamArena: module has no parameters")
+        dev = params[0].device
+        require_cuda(params[0], "ParamArena parameters")
+        offs, total = [], 0
+        for p in params:
+            offs.append(total)
+            total += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.params, self.offsets = params, offs
+        self.ranges = {}
+        with torch.no_grad():
+            for p, o in zip(params, offs):
+                n = p.numel()
+                view = self.flat[o:o + n].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+                p._lc2is_grad = self.grad[o:o + n].view(p.shape)
+                p.grad = None
+                self.ranges[id(p)] = (o, o + n)
+        self.numel = total
+
+    def attach_grads(self):
+        for p in self.params:
+            p.grad = p._lc2is_grad
+
+    def zero_grad(self, set_to_none: bool = True):
+        """set_to_none: the next backward overwrites (no memset needed); else zero the flat buffer."""
+        if set_to_none:
+            for p in self.params:
+                p.grad = None
+        else:
+            self.grad.zero_()
+            self.attach_grads()
+
+    def finalize_grads(self):
+        """After backward: parameters the graph never reached (e.g. CLIP's post_layernorm) get a zero gradient
+        so the flat buffer is fully defined for the fused optimizer / all-reduce."""
+        for p in self.params:
+            if p.grad is None:
+                p._lc2is_grad.zero_()
+                p.grad = p._lc2is_grad
+
+    def module_range(self, module: nn.Module):
+        lo, hi = None, None
+        for p in module.parameters():
+            r = self.ranges.get(id(p))
+            if r is None:
+                continue
+            lo = r[0] if lo is None else min(lo, r[0])
+            hi = r[1] if hi is None else max(hi, r[1])
+        return lo, hi

@@ -1,0 +1,429 @@
+"""CLIP image / text encoders on MI355X — drop-ins for the reference's ``model/encoder.py`` wrappers.
+
+Reference interface mirrored here:
+  ImageEncoderCLIP(in_size, patch_size=16).forward(pixel_values) -> [B,P,C]          model/encoder.py:11-47
+  ImageEncoderCLIPFull(...).forward(pixel_values) -> [B,P+1,C]                        model/encoder.py:49-85
+  TextEncoderCLIP(patch_size=16).forward(input_ids, attention_mask) -> [B,L,C]        model/encoder.py:87-102
+  TextEncoderCLIPPooler(...).forward(input_ids, attention_mask=None) -> [B,C]         model/encoder.py:104-119
+  .hidden_size() -> int
+Parameters live under ``enc.*`` with transformers-5.15 names (``embeddings.class_embedding``,
+``pre_layrnorm`` [sic], ``encoder.layers.{i}.self_attn.{q,k,v,out}_proj`` ...); the legacy
+``enc.vision_model.`` / ``enc.text_model.`` prefixes are accepted on load.
+
+The reference constructs these through ``from_pretrained(<hub name>)``; there is no network here, so the
+constructors build the same architecture with random init and weights arrive via ``load_state_dict``.
+
+Compute: the whole layer stack runs on the HIP kernels of ``liblc2is_hip.so`` (bf16 MFMA GEMMs with fused
+bias / quick_gelu / residual epilogues, fused attention, LayerNorm over an fp32 residual stream).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import torch
+from torch import nn
+
+from .. import ops
+from .base import HipModule, grad_buf, linear_bwd_params, require_cuda, vec_grad
+
+
+@dataclass
+class ClipArch:
+    hidden: int = 768
+    heads: int = 12
+    layers: int = 12
+    intermediate: int = 3072
+    eps: float = 1e-5
+    # text only
+    vocab: int = 49408
+    max_pos: int = 77
+    eos_token_id: int = 49407
+
+
+VIT_B16 = ClipArch(768, 12, 12, 3072)
+VIT_L14 = ClipArch(1024, 16, 24, 4096)
+TEXT_B = ClipArch(512, 8, 12, 2048)
+TEXT_L = ClipArch(768, 12, 12, 3072)
+
+
+# ---- parameter containers (names == transformers 5.15 CLIP) -------------------------------------------
+class _Attn(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.k_proj, self.v_proj, self.q_proj, self.out_proj = (nn.Linear(c, c) for _ in range(4))
+
+
+class _MLP(nn.Module):
+    def __init__(self, c, i):
+        super().__init__()
+        self.fc1, self.fc2 = nn.Linear(c, i), nn.Linear(i, c)
+
+
+class _Layer(nn.Module):
+    def __init__(self, a: ClipArch):
+        super().__init__()
+        self.self_attn = _Attn(a.hidden)
+        self.layer_norm1 = nn.LayerNorm(a.hidden, eps=a.eps)
+        self.mlp = _MLP(a.hidden, a.intermediate)
+        self.layer_norm2 = nn.LayerNorm(a.hidden, eps=a.eps)
+
+
+class _Stack(nn.Module):
+    def __init__(self, a: ClipArch):
+        super().__init__()
+        self.layers = nn.ModuleList([_Layer(a) for _ in range(a.layers)])
+
+
+class _VisionEmbeddings(nn.Module):
+    def __init__(self, a: ClipArch, image_size: int, patch: int):
+        super().__init__()
+        self.class_embedding = nn.Parameter(torch.randn(a.hidden))
+        self.patch_embedding = nn.Conv2d(3, a.hidden, patch, stride=patch, bias=False)
+        self.position_embedding = nn.Embedding((image_size // patch) ** 2 + 1, a.hidden)
+
+
+class _TextEmbeddings(nn.Module):
+    def __init__(self, a: ClipArch):
+        super().__init__()
+        self.token_embedding = nn.Embedding(a.vocab, a.hidden)
+        self.position_embedding = nn.Embedding(a.max_pos, a.hidden)
+
+
+class _VisionParams(nn.Module):
+    def __init__(self, a: ClipArch, image_size: int, patch: int):
+        super().__init__()
+        self.embeddings = _VisionEmbeddings(a, image_size, patch)
+        self.pre_layrnorm = nn.LayerNorm(a.hidden, eps=a.eps)
+        self.encoder = _Stack(a)
+        self.post_layernorm = nn.LayerNorm(a.hidden, eps=a.eps)  # part of the checkpoint; unused for tokens
+
+
+class _TextParams(nn.Module):
+    def __init__(self, a: ClipArch):
+        super().__init__()
+        self.embeddings = _TextEmbeddings(a)
+        self.encoder = _Stack(a)
+        self.final_layer_norm = nn.LayerNorm(a.hidden, eps=a.eps)
+
+
+def _clip_init(enc: nn.Module, a: ClipArch) -> None:
+    """transformers CLIPPreTrainedModel._init_weights, restated (initializer_factor = 1)."""
+    in_std = a.hidden ** -0.5 * (2 * a.layers) ** -0.5
+    out_std = a.hidden ** -0.5
+    fc_std = (2 * a.hidden) ** -0.5
+    with torch.no_grad():
+        for layer in enc.encoder.layers:
+            for n in ("q_proj", "k_proj", "v_proj"):
+                getattr(layer.self_attn, n).weight.normal_(0, in_std)
+                getattr(layer.self_attn, n).bias.zero_()
+            layer.self_attn.out_proj.weight.normal_(0, out_std)
+            layer.self_attn.out_proj.bias.zero_()
+            layer.mlp.fc1.weight.normal_(0, fc_std)
+            layer.mlp.fc2.weight.normal_(0, in_std)
+            layer.mlp.fc1.bias.zero_()
+            layer.mlp.fc2.bias.zero_()
+        emb = enc.embeddings
+        if hasattr(emb, "class_embedding"):
+            emb.class_embedding.normal_(0, a.hidden ** -0.5)
+            emb.patch_embedding.weight.normal_(0, 0.02)
+            emb.position_embedding.weight.normal_(0, 0.02)
+        else:
+            emb.token_embedding.weight.normal_(0, 0.02)
+            emb.position_embedding.weight.normal_(0, 0.02)
+
+
+# ---- the shared pre-LN layer stack -------------------------------------------------------------------
+def _stack_shadows(stack: _Stack, a: ClipArch, device):
+    """bf16 shadows for one encoder stack: fused QKV [3C,C] (+T), out/fc1/fc2 (+T), fused fp32 QKV bias."""
+    C, I = a.hidden, a.intermediate
+    bf = dict(dtype=torch.bfloat16, device=device)
+    per, entries = [], []
+    for layer in stack.layers:
+        at, mlp = layer.self_attn, layer.mlp
+        s = dict(wqkv=torch.empty(3 * C, C, **bf), wqkvT=torch.empty(C, 3 * C, **bf),
+                 bqkv=torch.empty(3 * C, dtype=torch.float32, device=device),
+                 wo=torch.empty(C, C, **bf), woT=torch.empty(C, C, **bf),
+                 w1=torch.empty(I, C, **bf), w1T=torch.empty(C, I, **bf),
+                 w2=torch.empty(C, I, **bf), w2T=torch.empty(I, C, **bf))
+        for j, proj in enumerate((at.q_proj, at.k_proj, at.v_proj)):
+            entries.append((proj.weight, s["wqkv"][j * C:(j + 1) * C], s["wqkvT"][:, j * C:(j + 1) * C]))
+            entries.append((proj.bias, s["bqkv"][j * C:(j + 1) * C], None))
+        entries.append((at.out_proj.weight, s["wo"], s["woT"]))
+        entries.append((mlp.fc1.weight, s["w1"], s["w1T"]))
+        entries.append((mlp.fc2.weight, s["w2"], s["w2T"]))
+        per.append(s)
+    return per, entries
+
+
+def _stack_fwd(x, stack: _Stack, sh, a: ClipArch, B: int, S: int, kbias, causal: bool, save: bool):
+    """x fp32 [B*S, C] residual stream -> (x_out fp32, saved list).  hf:modeling_clip.py:362-383 per layer."""
+    C, H = a.hidden, a.heads
+    D = C // H
+    scale = D ** -0.5
+    saved = []
+    for layer, s in zip(stack.layers, sh):
+        h, _, m1, r1 = ops.layernorm_fwd(x, layer.layer_norm1.weight, layer.layer_norm1.bias, a.eps, save_stats=save)
+        qkv, _, _ = ops.gemm_nt(h, s["wqkv"], s["bqkv"])
+        o, lse = ops.attention_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, H, S, S, D, scale, causal=causal,
+                                   kbias=kbias, save_lse=save)
+        _, x_mid, _ = ops.gemm_nt(o, s["wo"], layer.self_attn.out_proj.bias, resid=x, out_bf16=None, out_f32=True)
+        h2, _, m2, r2 = ops.layernorm_fwd(x_mid, layer.layer_norm2.weight, layer.layer_norm2.bias, a.eps,
+                                          save_stats=save)
+        act, _, z = ops.gemm_nt(h2, s["w1"], layer.mlp.fc1.bias, act=ops.ACT_QUICK_GELU, aux_out=True if save else None)
+        _, x_out, _ = ops.gemm_nt(act, s["w2"], layer.mlp.fc2.bias, resid=x_mid, out_bf16=None, out_f32=True)
+        if save:
+            saved.append((x, m1, r1, h, qkv, o, lse, x_mid, m2, r2, h2, z, act))
+        x = x_out
+    return x, saved
+
+
+def _stack_bwd(g32, g16, stack: _Stack, sh, saved, a: ClipArch, B: int, S: int, kbias, causal: bool):
+    """Backward of _stack_fwd.  g32/g16: gradient wrt the stack output (fp32 + bf16 twin).
+    Returns the gradient wrt the stack input as (fp32, bf16)."""
+    C, H = a.hidden, a.heads
+    D = C // H
+    scale = D ** -0.5
+    for layer, s, sv in zip(reversed(stack.layers), reversed(sh), reversed(saved)):
+        x, m1, r1, h, qkv, o, lse, x_mid, m2, r2, h2, z, act = sv
+        at, mlp = layer.self_attn, layer.mlp
+        # x_out = x_mid + fc2(quick_gelu(fc1(LN2(x_mid))))
+        linear_bwd_params(g16, act, mlp.fc2.weight, mlp.fc2.bias)
+        dz, _, _ = ops.gemm_nt(g16, s["w2T"], None, act=ops.ACT_DQUICK_GELU, aux_in=z)
+        linear_bwd_params(dz, h2, mlp.fc1.weight, mlp.fc1.bias)
+        dh2, _, _ = ops.gemm_nt(dz, s["w1T"], None)
+        dg, accg = vec_grad(layer.layer_norm2.weight)
+        db, _ = vec_grad(layer.layer_norm2.bias)
+        gm32, gm16, _, _ = ops.layernorm_bwd(dh2, x_mid, layer.layer_norm2.weight, m2, r2, dres=g32, dgamma=dg,
+                                             dbeta=db, accumulate=accg, need_param_grads=dg is not None)
+        # x_mid = x + out_proj(attn(qkv(LN1(x))))
+        linear_bwd_params(gm16, o, at.out_proj.weight, at.out_proj.bias)
+        do, _, _ = ops.gemm_nt(gm16, s["woT"], None)
+        dqkv = torch.empty_like(qkv)
+        ops.attention_bwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o, do, lse, B, H, S, S, D, scale, causal=causal,
+                          kbias=kbias, dq=dqkv[:, :C], dk=dqkv[:, C:2 * C], dv=dqkv[:, 2 * C:])
+        for j, proj in enumerate((at.q_proj, at.k_proj, at.v_proj)):
+            linear_bwd_params(dqkv[:, j * C:(j + 1) * C], h, proj.weight, proj.bias)
+        dh, _, _ = ops.gemm_nt(dqkv, s["wqkvT"], None)
+        dg, accg = vec_grad(layer.layer_norm1.weight)
+        db, _ = vec_grad(layer.layer_norm1.bias)
+        g32, g16, _, _ = ops.layernorm_bwd(dh, x, layer.layer_norm1.weight, m1, r1, dres=gm32, dgamma=dg, dbeta=db,
+                                           accumulate=accg, need_param_grads=dg is not None)
+    return g32, g16
+
+
+def _remap_legacy_keys(state_dict, prefix, inner: str):
+    """Accept pre-5.x transformers checkpoints: `enc.vision_model.X` / `enc.text_model.X` -> `enc.X`."""
+    legacy = prefix + "enc." + inner + "."
+    for k in [k for k in state_dict if k.startswith(legacy)]:
+        state_dict[prefix + "enc." + k[len(legacy):]] = state_dict.pop(k)
+    state_dict.pop(prefix + "enc.embeddings.position_ids", None)
+
+
+# ---- vision -------------------------------------------------------------------------------------------
+class _VisionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pixel_values, anchor, mod, keep_cls, save):
+        out, saved = mod._fwd(pixel_values, keep_cls, save)
+        ctx.mod, ctx.saved, ctx.keep_cls = mod, saved, keep_cls
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        ctx.mod._bwd(gout.contiguous(), ctx.saved, ctx.keep_cls)
+        ctx.saved = None
+        return None, None, None, None, None
+
+
+class ImageEncoderCLIP(HipModule):
+    """Drop-in for model/encoder.py:11-47 (ViT-B/16 for patch_size 16, ViT-L/14 for patch_size 14)."""
+
+    keep_cls = False
+
+    def __init__(self, in_size: int, patch_size: int = 16, arch: ClipArch | None = None) -> None:
+        super().__init__()
+        self.in_size, self.patch_size = in_size, patch_size
+        if arch is None:
+            if patch_size == 16:
+                arch = VIT_B16
+            elif patch_size == 14:
+                arch = VIT_L14
+            else:
+                raise ValueError("ImageEncoderCLIP: only patch_size 16 (ViT-B/16) and 14 (ViT-L/14) have defaults")
+        self.arch = arch
+        self.enc = _VisionParams(arch, in_size, patch_size)
+        _clip_init(self.enc, arch)
+
+    def hidden_size(self) -> int:
+        return self.arch.hidden
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        _remap_legacy_keys(state_dict, prefix, "vision_model")
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def _build_shadows(self, device):
+        a = self.arch
+        per, entries = _stack_shadows(self.enc.encoder, a, device)
+        k = 3 * self.patch_size ** 2
+        kpad = (k + 63) // 64 * 64
+        wp = torch.zeros(a.hidden, kpad, dtype=torch.bfloat16, device=device)
+        entries.append((self.enc.embeddings.patch_embedding.weight.view(a.hidden, k), wp[:, :k], None))
+        return dict(layers=per, wpatch=wp, kpad=kpad), entries
+
+    def _fwd(self, pixel_values, keep_cls, save):
+        require_cuda(pixel_values, "pixel_values")
+        a, sh = self.arch, self._ensure_ready()
+        B = pixel_values.shape[0]
+        G = self.in_size // self.patch_size
+        P = G * G
+        if pixel_values.shape[-1] != self.in_size or pixel_values.shape[-2] != self.in_size:
+            raise ValueError(f"Input image size ({pixel_values.shape[-2]}*{pixel_values.shape[-1]}) doesn't match "
+                             f"model ({self.in_size}*{self.in_size}).")  # hf:modeling_clip.py:204-207
+        emb = self.enc.embeddings
+        cols = ops.patchify(pixel_values.float().contiguous(), self.patch_size, sh["kpad"])
+        _, pe, _ = ops.gemm_nt(cols, sh["wpatch"], None, out_bf16=None, out_f32=True)
+        x0 = ops.vit_embed_fwd(pe, emb.class_embedding, emb.position_embedding.weight, B, P)
+        _, x, m0, r0 = ops.layernorm_fwd(x0, self.enc.pre_layrnorm.weight, self.enc.pre_layrnorm.bias, a.eps,
+                                         save_stats=save, out_bf16=None, out_f32=True)
+        x, saved = _stack_fwd(x, self.enc.encoder, sh["layers"], a, B, P + 1, None, False, save)
+        if keep_cls:
+            out = x.view(B, P + 1, a.hidden)
+        else:
+            out = torch.empty(B * P, a.hidden, dtype=torch.float32, device=x.device)
+            ops.rows_copy(x, P + 1, 1, P, 0, B, P, dst_f32=out)
+            out = out.view(B, P, a.hidden)
+        return out, (dict(cols=cols, x0=x0, m0=m0, r0=r0, layers=saved, B=B, P=P) if save else None)
+
+    def _bwd(self, gout, saved, keep_cls):
+        a, sh = self.arch, self._sh
+        B, P = saved["B"], saved["P"]
+        C = a.hidden
+        if keep_cls:
+            g32 = gout.reshape(B * (P + 1), C).float()
+        else:
+            g32 = torch.zeros(B * (P + 1), C, dtype=torch.float32, device=gout.device)
+            ops.rows_copy(gout.reshape(B * P, C).float().contiguous(), P, 0, P + 1, 1, B, P, dst_f32=g32)
+        g16 = ops.cast_bf16(g32)
+        g32, _ = _stack_bwd(g32, g16, self.enc.encoder, sh["layers"], saved["layers"], a, B, P + 1, None, False)
+        dg, accg = vec_grad(self.enc.pre_layrnorm.weight)
+        db, _ = vec_grad(self.enc.pre_layrnorm.bias)
+        dx0, _, _, _ = ops.layernorm_bwd(g32, saved["x0"], self.enc.pre_layrnorm.weight, saved["m0"], saved["r0"],
+                                         dgamma=dg, dbeta=db, accumulate=accg, want_bf16=False,
+                                         need_param_grads=dg is not None)
+        emb = self.enc.embeddings
+        gpos, accp = grad_buf(emb.position_embedding.weight)
+        gcls, accc = grad_buf(emb.class_embedding)
+        if accp != accc:
+            raise RuntimeError("lc2is_amd: inconsistent gradient state of the ViT embeddings")
+        dpatch = ops.vit_embed_bwd(dx0, gpos, gcls, B, P, accumulate=accp)
+        gw, accw = grad_buf(emb.patch_embedding.weight)
+        k = 3 * self.patch_size ** 2
+        if sh["kpad"] == k:
+            ops.gemm_tn(dpatch, saved["cols"], gw.view(C, k), accumulate=accw)
+        else:
+            tmp = ops.gemm_tn(dpatch, saved["cols"])
+            gw.view(C, k).copy_(tmp[:, :k]) if not accw else gw.view(C, k).add_(tmp[:, :k])
+
+    def forward(self, pixel_values: torch.Tensor) -> torch.Tensor:
+        anchor = self.enc.pre_layrnorm.weight
+        return _VisionFn.apply(pixel_values, anchor, self, self.keep_cls, torch.is_grad_enabled() and anchor.requires_grad)
+
+
+class ImageEncoderCLIPFull(ImageEncoderCLIP):
+    """Drop-in for model/encoder.py:49-85: same encoder, CLS token kept -> [B, P+1, C]."""
+
+    keep_cls = True
+
+
+# ---- text ---------------------------------------------------------------------------------------------
+class _TextFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, input_ids, attention_mask, anchor, mod, save):
+        out, saved = mod._fwd(input_ids, attention_mask, save)
+        ctx.mod, ctx.saved = mod, saved
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        ctx.mod._bwd(gout.contiguous(), ctx.saved)
+        ctx.saved = None
+        return None, None, None, None, None
+
+
+class TextEncoderCLIP(HipModule):
+    """Drop-in for model/encoder.py:87-102: CLIP text transformer, returns last_hidden_state [B,L,C]."""
+
+    def __init__(self, patch_size: int = 16, arch: ClipArch | None = None) -> None:
+        super().__init__()
+        self.patch_size = patch_size
+        if arch is None:
+            arch = TEXT_B if patch_size == 16 else TEXT_L
+        self.arch = arch
+        self.enc = _TextParams(arch)
+        _clip_init(self.enc, arch)
+
+    def hidden_size(self) -> int:
+        return self.arch.hidden
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        _remap_legacy_keys(state_dict, prefix, "text_model")
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def _build_shadows(self, device):
+        per, entries = _stack_shadows(self.enc.encoder, self.arch, device)
+        return dict(layers=per), entries
+
+    def _fwd(self, input_ids, attention_mask, save):
+        require_cuda(input_ids, "input_ids")
+        a, sh = self.arch, self._ensure_ready()
+        B, L = input_ids.shape
+        if L > a.max_pos:
+            raise ValueError(f"Sequence length must be less than max_position_embeddings (got `sequence length`: "
+                             f"{L} and max_position_embeddings: {a.max_pos}")  # hf CLIPTextEmbeddings.forward
+        emb = self.enc.embeddings
+        ids = input_ids.contiguous()
+        x = ops.text_embed_fwd(ids, emb.token_embedding.weight, emb.position_embedding.weight)
+        kbias = None
+        if attention_mask is not None:
+            kbias = torch.zeros(B, L, dtype=torch.float32, device=ids.device)
+            kbias.masked_fill_(attention_mask == 0, float("-inf"))
+        x, saved = _stack_fwd(x, self.enc.encoder, sh["layers"], a, B, L, kbias, True, save)
+        fl = self.enc.final_layer_norm
+        _, y, mf, rf = ops.layernorm_fwd(x, fl.weight, fl.bias, a.eps, save_stats=save, out_bf16=None, out_f32=True)
+        return y.view(B, L, a.hidden), (dict(ids=ids, kbias=kbias, xf=x, mf=mf, rf=rf, layers=saved, B=B, L=L)
+                                        if save else None)
+
+    def _bwd(self, gout, saved):
+        a, sh = self.arch, self._sh
+        B, L, C = saved["B"], saved["L"], a.hidden
+        fl = self.enc.final_layer_norm
+        dg, accg = vec_grad(fl.weight)
+        db, _ = vec_grad(fl.bias)
+        g32, g16, _, _ = ops.layernorm_bwd(gout.reshape(B * L, C).float().contiguous(), saved["xf"], fl.weight,
+                                           saved["mf"], saved["rf"], dgamma=dg, dbeta=db, accumulate=accg,
+                                           need_param_grads=dg is not None)
+        g32, _ = _stack_bwd(g32, g16, self.enc.encoder, sh["layers"], saved["layers"], a, B, L, saved["kbias"], True)
+        emb = self.enc.embeddings
+        if emb.token_embedding.weight.requires_grad:
+            gtok, acct = grad_buf(emb.token_embedding.weight)
+            gpos, accp = grad_buf(emb.position_embedding.weight)
+            if not acct:
+                gtok.zero_()  # the scatter uses atomics
+            if not accp:
+                gpos.zero_()
+            ops.text_embed_bwd(saved["ids"], g32, gtok, gpos, accumulate=True)
+
+    def forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
+        anchor = self.enc.final_layer_norm.weight
+        return _TextFn.apply(input_ids, attention_mask, anchor, self, torch.is_grad_enabled() and anchor.requires_grad)
+
+
+class TextEncoderCLIPPooler(TextEncoderCLIP):
+    """Drop-in for model/encoder.py:104-119: pooler_output = hidden state at the first EOS position
+    (hf:modeling_clip.py:572-581); the gather is plain indexing on top of the HIP last_hidden_state."""
+
+    def forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor = None) -> torch.Tensor:
+        anchor = self.enc.final_layer_norm.weight
+        hidden = _TextFn.apply(input_ids, attention_mask, anchor, self, torch.is_grad_enabled() and anchor.requires_grad)
+        eos = (input_ids == self.arch.eos_token_id).int().argmax(dim=-1)
+        return hidden[torch.arange(hidden.shape[0], device=hidden.device), eos]

@@ -43,6 +43,7 @@ _ARGTYPES = {
     "lc2is_head_upsample_ce": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, C.c_long, _F, _P],
     "lc2is_ce_nchw_fwd": [_P, _P, _P, _P, _I, _I, C.c_long, C.c_long, _P],
     "lc2is_ce_nchw_bwd": [_P, _P, _P, _P, _F, _P, _I, _I, C.c_long, C.c_long, _P],
+    "lc2is_upsample_bwd_nchw": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
 }
 _bound = {}
 
@@ -260,7 +261,7 @@ INTERP_BICUBIC, INTERP_BILINEAR = 0, 1
 
 class ShadowDesc(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("dstT", C.c_void_p), ("N", C.c_int), ("K", C.c_int),
-                ("ld_dst", C.c_int), ("ld_dstT", C.c_int), ("tile_start", C.c_int), ("reserved", C.c_int)]
+                ("ld_dst", C.c_int), ("ld_dstT", C.c_int), ("tile_start", C.c_int), ("flags", C.c_int)]
 
 
 class ShadowTable:
@@ -272,8 +273,15 @@ class ShadowTable:
         start = 0
         self._keep = []
         for i, (src, dst, dstT) in enumerate(entries):
-            _chk(src, torch.float32, "shadow src"); _chk(dst, torch.bfloat16, "shadow dst")
+            if src.dim() == 1:  # vectors are copied as [1,K] rows
+                src = src.unsqueeze(0)
+                dst = dst.unsqueeze(0) if dst is not None and dst.dim() == 1 else dst
+            f32copy = dst is not None and dst.dtype == torch.float32
+            _chk(src, torch.float32, "shadow src")
+            _chk(dst, torch.float32 if f32copy else torch.bfloat16, "shadow dst")
             _chk(dstT, torch.bfloat16, "shadow dstT")
+            if f32copy and dstT is not None:
+                raise RuntimeError("lc2is_amd: fp32 shadow copies have no transposed twin")
             if not src.is_contiguous():
                 raise RuntimeError("lc2is_amd: shadow source must be contiguous")
             N, K = src.shape
@@ -283,7 +291,7 @@ class ShadowTable:
                 raise RuntimeError("lc2is_amd: shadow dst shape mismatch")
             if dstT is not None and tuple(dstT.shape) != (K, N):
                 raise RuntimeError("lc2is_amd: shadow dstT shape mismatch")
-            descs[i] = ShadowDesc(src.data_ptr(), _ptr(dst), _ptr(dstT), N, K, _ld(dst), _ld(dstT), start, 0)
+            descs[i] = ShadowDesc(src.data_ptr(), _ptr(dst), _ptr(dstT), N, K, _ld(dst), _ld(dstT), start, int(f32copy))
             start += ((N + 63) // 64) * ((K + 63) // 64)
             self._keep.append((src, dst, dstT))
         self.n = len(entries)
@@ -431,3 +439,14 @@ def ce_nchw_bwd(logits, labels, lse, grad_scale_dev, grad_scale: float, ignore_i
     _lib.check(_fn("lc2is_ce_nchw_bwd")(_ptr(logits), _ptr(labels), _ptr(lse), _ptr(grad_scale_dev), grad_scale,
                                         _ptr(d), B, Cc, H * W, ignore_index, _stream()), "ce_nchw_bwd")
     return d
+
+
+def upsample_bwd_nchw(dhi, B: int, h: int, w: int, C: int, S: int, mode: int, ld: int):
+    """dhi fp32 NCHW [B,C,h*S,w*S] -> dlo fp32 [B*h*w, ld] (zero padded columns)."""
+    _chk(dhi, torch.float32, "dhi", 4)
+    if not dhi.is_contiguous() or tuple(dhi.shape) != (B, C, h * S, w * S):
+        raise RuntimeError("lc2is_amd.upsample_bwd_nchw: dhi must be contiguous [B,C,h*S,w*S]")
+    dlo = torch.zeros((B * h * w, ld), dtype=torch.float32, device=dhi.device)
+    _lib.check(_fn("lc2is_upsample_bwd_nchw")(_ptr(dhi), _ptr(dlo), ld, B, h, w, C, S, mode, _stream()),
+               "upsample_bwd_nchw")
+    return dlo
