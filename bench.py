@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training-step images/sec of BaseModelWithText (ViT-B/16 + CLIP text + cross-attention
+decoder + fused head/CE) at 512x512, 151 classes, bf16 compute, batch 32 per GPU — BASELINE.json configs[1]
+(N=1) / configs[2] (N>1, data parallel over RCCL).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py ...)
+
+A "step" is one full iteration of the reference's train loop (engine.py:78-104) on one synthetic batch that is
+already resident in HBM: zero_grad -> forward -> CE -> backward (-> gradient all-reduce) -> optimizer step.
+Rank 0 prints ONE JSON line (see the driver contract in the task statement) including
+  roofline     — the dominant kernel (bf16 MFMA NT GEMM): algorithmic FLOPs / HIP-event-timed duration of
+                 every launch of it inside the timed steps, against the 2.5 PFLOP/s dense bf16 peak;
+  cpu_baseline — the CPU oracle's train step timed on this box's host cores on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+
+
+def synth_batch(B, in_size, out_size, L, seed, device):
+    """N(0,1) pixels, uniform labels, BOS + 10 tokens + EOS + pads (mask 0)."""
+    g = torch.Generator().manual_seed(seed)
+    pixel_values = torch.randn(B, 3, in_size, in_size, generator=g)
+    labels = torch.randint(0, 151, (B, out_size, out_size), generator=g)
+    ids = torch.full((B, L), 49407, dtype=torch.int64)
+    ids[:, 0] = 49406
+    n_tok = max(1, L - 6)
+    ids[:, 1:1 + n_tok] = torch.randint(1, 49405, (B, n_tok), generator=g)
+    mask = torch.zeros(B, L, dtype=torch.int64)
+    mask[:, :n_tok + 2] = 1
+    inputs = dict(pixel_values=pixel_values.to(device), input_ids=ids.to(device), attention_mask=mask.to(device))
+    return inputs, labels.to(device)
+
+
+class GemmTimer:
+    """HIP-event timing of every gemm_nt launch (recorded on the stream the kernels are launched on)."""
+
+    def __init__(self):
+        from lc2is_amd import ops
+        self.ops = ops
+        self.records = []
+        self._orig = ops.gemm_nt
+
+    def __enter__(self):
+        orig, recs = self._orig, self.records
+
+        def timed(a, w, bias=None, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig(a, w, bias, **kw)
+            e1.record()
+            recs.append((e0, e1, 2.0 * a.shape[0] * w.shape[0] * a.shape[1]))
+            return out
+
+        self.ops.gemm_nt = timed  # callers resolve `ops.gemm_nt` at call time
+        return self
+
+    def __exit__(self, *exc):
+        self.ops.gemm_nt = self._orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        t = sum(e0.elapsed_time(e1) for e0, e1, _ in self.records) * 1e-3
+        fl = sum(f for _, _, f in self.records)
+        return dict(launches=len(self.records), seconds=t, flops=fl)
+
+
+def cpu_baseline(arch_kwargs, in_size, out_size, L, sample_images, steps):
+    """The CPU oracle (oracle/ref_cpu.py: fp32 restatement of the reference path, pinned by golden vectors)
+    running the same train step on this box's host cores."""
+    from oracle import ref_cpu as O
+    import lc2is_amd.nn as N
+    torch.manual_seed(1024)
+    m = N.BaseModelWithText(16, in_size, out_size, **arch_kwargs)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    va, ta = m.vision_encoder.arch, m.text_encoder.arch
+    cfg = O.BaseCfg(in_size=in_size, out_size=out_size, patch=16, vision=O.ClipCfg(va.hidden, va.heads, va.layers, patch=16),
+                    text=O.ClipCfg(ta.hidden, ta.heads, ta.layers, eos_token_id=ta.eos_token_id),
+                    dec_heads=m.vision_decoder.layers[0].nhead, dec_layers=m.vision_decoder.num_layers)
+    del m
+    inputs, labels = synth_batch(sample_images, in_size, out_size, L, 2, "cpu")
+    cores = torch.get_num_threads()
+    O.train_step_sgd(sd, inputs, labels, cfg, 1e-5)  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        O.train_step_sgd(sd, inputs, labels, cfg, 1e-5)
+    dt = time.perf_counter() - t0
+    return dict(value=sample_images * steps / dt, unit="images/s", cores=cores, kind="port",
+                sample=f"{steps} train steps of batch {sample_images} at {in_size}x{in_size} (fp32 oracle, 1 warm-up)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU")
+    ap.add_argument("--in-size", type=int, default=512)
+    ap.add_argument("--text-len", type=int, default=16)
+    ap.add_argument("--optimizer", default="sgd")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-images", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    reducer = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import lc2is_amd.nn as N
+    from lc2is_amd.dp import GradReducer
+    from lc2is_amd.step import TrainStep
+
+    in_size, out_size = args.in_size, 4 * (args.in_size // 16)
+    torch.manual_seed(1024)  # evaluate.py:24 default seed; identical replica on every rank
+    model = N.BaseModelWithText(patch_size=16, in_size=in_size, out_size=out_size).to(dev).train()
+    if world > 1:
+        reducer = GradReducer()
+    ts = TrainStep(model, optimizer=args.optimizer, lr=1e-5, reducer=reducer)  # all_args.sh:15 LR
+    if world > 1:
+        reducer.broadcast_params(ts.arena.flat, src=0)
+    inputs, labels = synth_batch(args.batch, in_size, out_size, args.text_len, 2 + rank, dev)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = ts.step(inputs, labels)
+    sync()
+    timer = GemmTimer()
+    t0 = time.perf_counter()
+    with timer:
+        for _ in range(args.steps):
+            loss = ts.step(inputs, labels)
+        sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    gsum = timer.summary()
+    loss_val = float(loss.item())
+
+    if rank == 0:
+        n_img = args.batch * world * args.steps
+        achieved = gsum["flops"] / gsum["seconds"] / 1e12 if gsum["seconds"] > 0 else 0.0
+        out = {
+            "metric": "training-step images/sec (512x512, ADE20K-150)", "value": n_img / dt, "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"BaseModelWithText ViT-B/16 + CLIP-text + decoder + fused head/CE train step, "
+                                   f"{in_size}x{in_size}, 151 classes, text len {args.text_len}, {args.optimizer}",
+                       "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                       "parallelism": f"dp{world}", "params_M": round(ts.arena.numel / 1e6, 2)},
+            "final_loss": loss_val,
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel (all bf16 NT GEMM launches of the timed steps)",
+                         "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                         "launches_per_step": gsum["launches"] / max(args.steps, 1),
+                         "avg_launch_us": gsum["seconds"] / max(gsum["launches"], 1) * 1e6,
+                         "gemm_nt_time_share": gsum["seconds"] / dt},
+        }
+        if not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline({}, in_size, out_size, args.text_len, args.cpu_images, args.cpu_steps)
+            except Exception as e:  # the baseline is a reported side number; never lose the GPU line over it
+                out["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

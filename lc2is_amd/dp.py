@@ -1,0 +1,97 @@
+"""Data-parallel gradient reduction over RCCL/xGMI (NEW functionality — the reference is single-device,
+SURVEY.md §2 row 19 / §8e).
+
+One process per GPU; every rank holds a full replica and its own B images.  Gradients live in ONE flat fp32
+arena (``ParamArena.grad``); ``GradReducer`` all-reduces (sum) contiguous slices of it as soon as the module
+that owns a slice has finished its backward — head -> decoder -> vision/text — so the collective for the
+late layers' gradients runs on RCCL's stream while the earlier layers' backward kernels still execute
+(overlap without a tracing compiler: the backward order is ours to know).  The 1/world_size average is folded
+into the fused optimizer kernel's ``grad_scale``.
+
+xGMI note: 157 M fp32 gradients = 628 MB; slices are whole modules (vision 343 MB, text 253 MB, decoder 30 MB,
+head 3 MB), i.e. few large collectives — per-link-bound rings want large messages, not 25 MB DDP buckets.
+
+The class only needs ``torch.distributed`` and flat tensors, so the same code runs under ``gloo`` on CPU
+tensors (tests/test_dp_gloo.py).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+class GradReducer:
+    def __init__(self, process_group=None, max_chunk_elems: int = 64 * 1024 * 1024) -> None:
+        if not dist.is_available() or not dist.is_initialized():
+            raise RuntimeError("GradReducer needs an initialised torch.distributed process group")
+        self.group = process_group
+        self.world_size = dist.get_world_size(process_group)
+        self.max_chunk = max_chunk_elems
+        self._pending = []
+        self._flat = None
+        self._done = set()
+        self._module_ranges = {}
+
+    # -- wiring ------------------------------------------------------------------------------------------------
+    def attach(self, model, arena) -> None:
+        """Register per-module slices of the arena and the modules' backward-complete callbacks."""
+        from .nn.base import HipModule
+        self._flat = arena.grad
+        self._arena = arena
+        tops = [m for m in model.children() if isinstance(m, HipModule)]
+        owned = set()
+        for m in tops:
+            ps = list(m.parameters())
+            owned.update(id(p) for p in ps)
+            self._module_ranges[id(m)] = (m, self._merge([arena.ranges[id(p)] for p in ps]), ps)
+            m._grad_ready_cb = self._on_module_done
+        rest = [p for p in model.parameters() if id(p) not in owned]  # e.g. class_prototypes of the composition
+        self._module_ranges[id(model)] = (model, self._merge([arena.ranges[id(p)] for p in rest]), rest)
+        model._grad_ready_cb = self._on_module_done
+
+    @staticmethod
+    def _merge(ranges):
+        out = []
+        for lo, hi in sorted(ranges):
+            lo_al = lo
+            if out and lo_al - out[-1][1] < 64:  # arena padding between neighbours
+                out[-1][1] = hi
+            else:
+                out.append([lo_al, hi])
+        return [(a, b) for a, b in out]
+
+    # -- per step ------------------------------------------------------------------------------------------------
+    def begin_step(self) -> None:
+        self._pending.clear()
+        self._done.clear()
+
+    def _on_module_done(self, module) -> None:
+        key = id(module)
+        if key in self._done or key not in self._module_ranges:
+            return
+        self._done.add(key)
+        _, ranges, params = self._module_ranges[key]
+        for p in params:  # parameters the graph never reached still need defined (zero) gradients
+            if p.grad is None:
+                p._lc2is_grad.zero_()
+                p.grad = p._lc2is_grad
+        self.reduce_ranges(self._flat, ranges)
+
+    def reduce_ranges(self, flat: torch.Tensor, ranges) -> None:
+        for lo, hi in ranges:
+            for a in range(lo, hi, self.max_chunk):
+                b = min(a + self.max_chunk, hi)
+                self._pending.append(dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish_step(self) -> None:
+        """Reduce whatever has not been reduced yet, then make the compute stream wait for every collective."""
+        for key, (_, ranges, _) in self._module_ranges.items():
+            if key not in self._done:
+                self._done.add(key)
+                self.reduce_ranges(self._flat, ranges)
+        for w in self._pending:
+            w.wait()
+        self._pending.clear()
+
+    def broadcast_params(self, flat_params: torch.Tensor, src: int = 0) -> None:
+        dist.broadcast(flat_params, src=src, group=self.group)

@@ -34,6 +34,7 @@ class HipModule(nn.Module):
         self._sh_versions = None
         self._sh_device = None
         self._sh_ptrs = []
+        self._grad_ready_cb = None  # set by dp.GradReducer: called when this module's backward is complete
 
     # subclasses: return (namespace_dict, entries) where entries = [(param, dst, dstT)]
     def _build_shadows(self, device):  # pragma: no cover - abstract
@@ -63,6 +64,10 @@ class HipModule(nn.Module):
 
     def _post_refresh(self):
         pass
+
+    def _grads_ready(self):
+        if self._grad_ready_cb is not None:
+            self._grad_ready_cb(self)
 
     def invalidate_shadows(self):
         """Call after changing parameters behind torch's back (the fused optimizer kernels do)."""

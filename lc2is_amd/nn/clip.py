@@ -323,6 +323,7 @@ class ImageEncoderCLIP(HipModule):
         else:
             tmp = ops.gemm_tn(dpatch, saved["cols"])
             gw.view(C, k).copy_(tmp[:, :k]) if not accw else gw.view(C, k).add_(tmp[:, :k])
+        self._grads_ready()
 
     def forward(self, pixel_values: torch.Tensor) -> torch.Tensor:
         anchor = self.enc.pre_layrnorm.weight
@@ -412,6 +413,7 @@ class TextEncoderCLIP(HipModule):
             if not accp:
                 gpos.zero_()
             ops.text_embed_bwd(saved["ids"], g32, gtok, gpos, accumulate=True)
+        self._grads_ready()
 
     def forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
         anchor = self.enc.final_layer_norm.weight

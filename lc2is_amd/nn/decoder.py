@@ -290,6 +290,7 @@ class DecoderBlock(HipModule):
         dmem = torch.zeros(B * Sk, Ckv, dtype=torch.float32, device=gout.device)
         for layer, s, sv in zip(reversed(self.layers), reversed(sh["layers"]), reversed(saved["layers"])):
             g32, g16 = _layer_bwd(g32, g16, dmem, saved["mem16"], layer, s, sv, B, Sq, Sk, saved["kbias"])
+        self._grads_ready()
         return g32.view(B, Sq, C), dmem.view(B, Sk, Ckv)
 
     def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,

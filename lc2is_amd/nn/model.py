@@ -188,6 +188,8 @@ class BaseModelWithText(HipModule):
                 gp.add_(dp[:K])
             else:
                 gp.copy_(dp[:K])
+        pp._grads_ready()
+        self._grads_ready()
         return ddec.view(B, P, C)
 
     # -- composition -----------------------------------------------------------------------------------------
