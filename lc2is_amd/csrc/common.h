@@ -64,6 +64,33 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + (bid >> 3);
 }
 
+namespace {
+// out[c] (+)= sum_{k < nparts} ws[k*stride + c] for c < W.  Block = 64 columns x 16 row groups (1024 threads):
+// coalesced 256-byte reads, 16-way parallel over the partials, fixed summation order (reproducible).
+// grid.x = ceil(W/64); grid.y selects an (ws, out) pair offset by (y*ws_off, out1 if y==1).
+__global__ __launch_bounds__(1024) void partials_reduce_kernel(const float* __restrict__ ws, int nparts,
+                                                                size_t stride, size_t ws_off_y, int W, float* out0,
+                                                                float* out1, int accumulate) {
+  __shared__ float red[16][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
+  float* out = blockIdx.y ? out1 : out0;
+  if (!out) return;
+  const float* w = ws + blockIdx.y * ws_off_y;
+  float s = 0.f;
+  if (c < W)
+    for (int k = ry; k < nparts; k += 16) s += w[(size_t)k * stride + c];
+  red[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && c < W) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[i][cx];
+    out[c] = accumulate ? out[c] + t : t;
+  }
+}
+}  // namespace
+
 static inline int lc2is_check_launch() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? LC2IS_OK : LC2IS_ERR_LAUNCH;

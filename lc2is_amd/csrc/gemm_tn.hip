@@ -302,7 +302,7 @@ extern "C" int lc2is_colsum_bf16(const void* dY, int ldy, float* db, int M, int 
                      ldy, (float*)workspace, M, N);
   int rc = lc2is_check_launch();
   if (rc) return rc;
-  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, stream,
-                     (const float*)workspace, parts, N, db, accumulate);
+  hipLaunchKernelGGL(partials_reduce_kernel, dim3((N + 63) / 64, 1), dim3(1024), 0, stream,
+                     (const float*)workspace, parts, (size_t)N, (size_t)0, N, db, (float*)nullptr, accumulate);
   return lc2is_check_launch();
 }

@@ -200,6 +200,162 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_ce_kernel(HeadArgs p) {
   }
 }
 
+// ---- fast path: bicubic, S == 4 (the headline configuration) ------------------------------------------
+// For S = 4 the output pixels Y in [4a+2, 4a+6) share one tap row set {a-1..a+2} and differ only in the
+// fractional weights t in {1/8, 3/8, 5/8, 7/8}.  Tiles are shifted by 2 pixels so they hold exactly 4x4 such
+// groups; a wave loads a group's 4x4 low-res cells into REGISTERS once (48 values per lane, lanes = channels),
+// evaluates its 16 pixels with separable row/column mixes, accumulates the gradient for the 16 cells in
+// registers, and touches LDS only for the final 48 adds per group (16x fewer LDS reads / atomics than the
+// generic kernel).
+constexpr int F4 = 7;  // footprint edge: 4 groups + 3
+
+__global__ __launch_bounds__(HEAD_THREADS) void head_ce_s4_kernel(HeadArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tiles_x = (p.W + 2 + HT - 1) / HT, tiles_y = (p.H + 2 + HT - 1) / HT;
+  const int b = blockIdx.x / (tiles_x * tiles_y);
+  const int tyi = (blockIdx.x / tiles_x) % tiles_y, txi = blockIdx.x % tiles_x;
+  const int a0 = 4 * tyi - 1, b0 = 4 * txi - 1;  // "floor" lo index of the tile's first group row / column
+  const int Cp = p.ld;
+  float* s_lo = (float*)smem;
+  float* s_dlo = s_lo + F4 * F4 * Cp;
+  const int fsize = F4 * F4 * Cp;
+  for (int i = tid * 4; i < fsize; i += HEAD_THREADS * 4) {
+    const int cell = i / Cp, c = i % Cp;
+    int ry = a0 - 1 + cell / F4, rx = b0 - 1 + cell % F4;
+    ry = ry < 0 ? 0 : (ry > p.h - 1 ? p.h - 1 : ry);
+    rx = rx < 0 ? 0 : (rx > p.w - 1 ? p.w - 1 : rx);
+    *reinterpret_cast<float4*>(s_lo + i) =
+        *reinterpret_cast<const float4*>(p.lo + (((size_t)b * p.h + ry) * p.w + rx) * p.ld + c);
+    if (p.dlo) *reinterpret_cast<float4*>(s_dlo + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  // weights of the four phases (identical for rows and columns)
+  float wt[4][4];
+#pragma unroll
+  for (int ph = 0; ph < 4; ++ph) {
+    const float t = 0.125f + 0.25f * (float)ph;
+    wt[ph][0] = cubic2(t + 1.f); wt[ph][1] = cubic1(t); wt[ph][2] = cubic1(1.f - t); wt[ph][3] = cubic2(2.f - t);
+  }
+  __syncthreads();
+
+  const bool c_ok[3] = {lane < p.C, lane + 64 < p.C, lane + 128 < p.C};
+  const float NEG = -__builtin_inff();
+  // labels of this wave's 32 pixels: lane -> (group lane>>4, py (lane>>2)&3, px lane&3)
+  int my_label = -1;
+  {
+    const int gi = 2 * wid + ((lane >> 4) & 1), gy = gi >> 2, gx = gi & 3;
+    const int Y = 4 * (a0 + gy) + 2 + ((lane >> 2) & 3), X = 4 * (b0 + gx) + 2 + (lane & 3);
+    if (lane < 32 && p.labels && Y >= 0 && X >= 0 && Y < p.H && X < p.W) {
+      const int64_t lab64 = p.labels[((size_t)b * p.H + Y) * p.W + X];
+      my_label = (lab64 == (int64_t)p.ignore_index || lab64 < 0 || lab64 >= p.C) ? -1 : (int)lab64;
+    }
+  }
+  float loss_acc = 0.f, cnt_acc = 0.f;
+
+#pragma unroll 1
+  for (int g2 = 0; g2 < 2; ++g2) {
+    const int gi = 2 * wid + g2, gy = gi >> 2, gx = gi & 3;
+    const int Yb = 4 * (a0 + gy) + 2, Xb = 4 * (b0 + gx) + 2;
+    if (Yb >= p.H || Xb >= p.W || Yb + 3 < 0 || Xb + 3 < 0) continue;  // wave-uniform
+    float v[4][4][3], dacc[4][4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float* cp = s_lo + ((gy + i) * F4 + gx + j) * Cp + lane;
+        v[i][j][0] = cp[0]; v[i][j][1] = cp[64]; v[i][j][2] = cp[128];
+        dacc[i][j][0] = 0.f; dacc[i][j][1] = 0.f; dacc[i][j][2] = 0.f;
+      }
+#pragma unroll
+    for (int py = 0; py < 4; ++py) {
+      const int Y = Yb + py;
+      float r[4][3], tq[4][3];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          r[j][k] = wt[py][0] * v[0][j][k] + wt[py][1] * v[1][j][k] + wt[py][2] * v[2][j][k] + wt[py][3] * v[3][j][k];
+          tq[j][k] = 0.f;
+        }
+      if (Y >= 0 && Y < p.H) {
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+          const int X = Xb + px;
+          if (X < 0 || X >= p.W) continue;  // wave-uniform
+          float lg[3];
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            lg[k] = wt[px][0] * r[0][k] + wt[px][1] * r[1][k] + wt[px][2] * r[2][k] + wt[px][3] * r[3][k];
+          if (p.hi_out) {
+            const size_t plane = (size_t)p.H * p.W;
+            float* o = p.hi_out + ((size_t)b * p.C) * plane + (size_t)Y * p.W + X;
+            if (c_ok[0]) o[(size_t)lane * plane] = lg[0];
+            if (c_ok[1]) o[(size_t)(lane + 64) * plane] = lg[1];
+            if (c_ok[2]) o[(size_t)(lane + 128) * plane] = lg[2];
+          }
+          if (!p.loss_sum) continue;
+          const int label = __shfl(my_label, 16 * g2 + 4 * py + px, 64);
+          float m = fmaxf(fmaxf(c_ok[0] ? lg[0] : NEG, c_ok[1] ? lg[1] : NEG), c_ok[2] ? lg[2] : NEG);
+          m = wave_max(m);
+          float e[3];
+          e[0] = c_ok[0] ? __expf(lg[0] - m) : 0.f;
+          e[1] = c_ok[1] ? __expf(lg[1] - m) : 0.f;
+          e[2] = c_ok[2] ? __expf(lg[2] - m) : 0.f;
+          const float ssum = wave_sum(e[0] + e[1] + e[2]);
+          if (label < 0) continue;
+          const int lsel = label >> 6, llane = label & 63;
+          const float vsel = lsel == 0 ? lg[0] : (lsel == 1 ? lg[1] : lg[2]);
+          loss_acc += (m + __logf(ssum)) - __shfl(vsel, llane, 64);
+          cnt_acc += 1.f;
+          if (p.dlo) {
+            const float inv = p.gscale / ssum;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              const float gk = e[k] * inv - ((lsel == k && lane == llane) ? p.gscale : 0.f);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) tq[j][k] += wt[px][j] * gk;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) dacc[i][j][k] += wt[py][i] * tq[j][k];
+    }
+    if (p.dlo) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float* cp = s_dlo + ((gy + i) * F4 + gx + j) * Cp + lane;
+          if (c_ok[0]) lds_add(cp, dacc[i][j][0]);
+          if (c_ok[1]) lds_add(cp + 64, dacc[i][j][1]);
+          if (c_ok[2]) lds_add(cp + 128, dacc[i][j][2]);
+        }
+    }
+  }
+
+  if (p.loss_sum && lane == 0 && cnt_acc > 0.f) {
+    atomicAdd(p.loss_sum, loss_acc);
+    atomicAdd(p.loss_sum + 1, cnt_acc);
+  }
+  if (p.dlo) {
+    __syncthreads();
+    for (int i = tid; i < fsize; i += HEAD_THREADS) {
+      const int cell = i / Cp, c = i % Cp;
+      if (c >= p.C) continue;
+      int ry = a0 - 1 + cell / F4, rx = b0 - 1 + cell % F4;
+      ry = ry < 0 ? 0 : (ry > p.h - 1 ? p.h - 1 : ry);
+      rx = rx < 0 ? 0 : (rx > p.w - 1 ? p.w - 1 : rx);
+      const float val = s_dlo[i];
+      if (val != 0.f) atomicAdd(p.dlo + (((size_t)b * p.h + ry) * p.w + rx) * p.ld + c, val);
+    }
+  }
+}
+
 // ---- generic pieces for the drop-in (unfused) path -----------------------------------------------------
 // softmax cross-entropy over NCHW fp32 logits: per-pixel lse + loss; backward writes dlogits NCHW.
 __global__ __launch_bounds__(256) void ce_nchw_fwd_kernel(const float* __restrict__ logits,
@@ -329,6 +485,19 @@ extern "C" int lc2is_head_upsample_ce(const float* scores_lo, int ld, const int6
                             hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess)
       return LC2IS_ERR_LAUNCH;
     attr_set = true;
+  }
+  if (mode == LC2IS_INTERP_BICUBIC && S == 4) {
+    static bool attr4 = false;
+    const int lds4 = 2 * F4 * F4 * ld * (int)sizeof(float);
+    if (!attr4) {
+      if (hipFuncSetAttribute((const void*)head_ce_s4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              2 * F4 * F4 * CMAX * (int)sizeof(float)) != hipSuccess)
+        return LC2IS_ERR_LAUNCH;
+      attr4 = true;
+    }
+    const int t4 = ((H + 2 + HT - 1) / HT) * ((W + 2 + HT - 1) / HT);
+    hipLaunchKernelGGL(head_ce_s4_kernel, dim3(B * t4), dim3(HEAD_THREADS), lds4, stream, a);
+    return lc2is_check_launch();
   }
   const int tiles = ((H + HT - 1) / HT) * ((W + HT - 1) / HT);
   if (mode == LC2IS_INTERP_BICUBIC)
