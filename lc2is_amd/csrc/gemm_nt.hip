@@ -31,9 +31,168 @@ struct GemmNtArgs {
   float* out_f32; int ldf;
   bf16_t* aux_out; int ldy;
   int M, N, K, act;
+  int staged_epi;  // bf16 epilogue traffic through LDS (needs N % 8 == 0 and 8-element-aligned leading dims)
 };
 
 __device__ __forceinline__ float sigmoidf_fast(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+template <int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void gemm_epilogue(const GemmNtArgs& p, f32x4_t (&acc)[TN][TM], int m0, int n0, int wm,
+                                              int wn, int lane) {
+  const int frow = lane & 15, g = lane >> 4;
+  // ---- epilogue: lane holds C[m][n..n+3], n = 4*(lane>>4) within the 16-wide sub-tile ----
+  const int act = p.act;
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int n = n0 + wn * WN + i * 16 + g * 4;
+    if (n >= p.N) continue;
+    f32x4_t bv = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bv = *(const f32x4_t*)(p.bias + n);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int m = m0 + wm * WM + j * 16 + frow;
+      if (m >= p.M) continue;
+      f32x4_t v = acc[i][j] + bv;
+      if (act == LC2IS_ACT_QUICK_GELU || act == LC2IS_ACT_RELU) {
+        if (p.aux_out) {
+          i32x2_t pk = {(int)pack_bf16x2(v[0], v[1]), (int)pack_bf16x2(v[2], v[3])};
+          *(i32x2_t*)(p.aux_out + (size_t)m * p.ldy + n) = pk;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          v[r] = (act == LC2IS_ACT_RELU) ? fmaxf(v[r], 0.f) : v[r] * sigmoidf_fast(1.702f * v[r]);
+      } else if (act == LC2IS_ACT_DQUICK_GELU || act == LC2IS_ACT_DRELU) {
+        const i32x2_t zk = *(const i32x2_t*)(p.aux_in + (size_t)m * p.ldx + n);
+        float z[4] = {bf16_to_f32((bf16_t)(zk[0] & 0xffff)), bf16_to_f32((bf16_t)((unsigned)zk[0] >> 16)),
+                      bf16_to_f32((bf16_t)(zk[1] & 0xffff)), bf16_to_f32((bf16_t)((unsigned)zk[1] >> 16))};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (act == LC2IS_ACT_DRELU) {
+            v[r] = z[r] > 0.f ? v[r] : 0.f;
+          } else {
+            const float s = sigmoidf_fast(1.702f * z[r]);
+            v[r] *= s * (1.f + 1.702f * z[r] * (1.f - s));
+          }
+        }
+      }
+      if (p.resid) v += *(const f32x4_t*)(p.resid + (size_t)m * p.ldr + n);
+      if (p.out_f32) *(f32x4_t*)(p.out_f32 + (size_t)m * p.ldf + n) = v;
+      if (p.out_bf16) {
+        i32x2_t pk = {(int)pack_bf16x2(v[0], v[1]), (int)pack_bf16x2(v[2], v[3])};
+        *(i32x2_t*)(p.out_bf16 + (size_t)m * p.ldo + n) = pk;
+      }
+    }
+  }
+}
+
+// LDS-staged epilogue for the LDS-DMA kernels (WN == 64): every bf16 tensor touched by the epilogue (saved
+// pre-activation in/out, bf16 output) moves between HBM and the wave as whole 128-byte row segments (16 B per
+// lane, 8 rows per wave instruction) through a private per-wave LDS patch, instead of 8-byte pieces whose
+// 32-byte row fragments cost partial-line writes.  fp32 residual / output keep the direct 16-B (64 B per row)
+// form.  Only in-order LDS traffic of one wave touches a patch, so no barrier is needed.
+template <int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void gemm_epilogue_lds(const GemmNtArgs& p, f32x4_t (&acc)[TN][TM], int m0, int n0, int wm,
+                                                  int wn, int lane, int wid, char* smem) {
+  static_assert(WN == 64 && TM % 4 == 0, "staged epilogue expects 64-column wave tiles");
+  constexpr int PITCH = 144;                 // 128 B of data + 16: conflict-free ds_write_b64 / ds_read_b128
+  char* patch = smem + wid * (64 * PITCH);
+  const int frow = lane & 15, g = lane >> 4;
+  const int srow = lane >> 3, sch = lane & 7;  // flush mapping: 8 rows x 8 chunks per wave instruction
+  const int act = p.act;
+  const int nw = n0 + wn * WN;
+  const bool col_ok = (nw + sch * 8) < p.N;
+
+#pragma unroll
+  for (int jg = 0; jg < TM / 4; ++jg) {
+    const int mrow0 = m0 + wm * WM + jg * 64;
+    if (mrow0 >= p.M) break;  // wave-uniform
+    // ---- (A) saved pre-activation for the derivative epilogues: HBM -> patch (coalesced) ----
+    if (act == LC2IS_ACT_DQUICK_GELU || act == LC2IS_ACT_DRELU) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int r = it * 8 + srow, m = mrow0 + r;
+        i32x4_t v = {0, 0, 0, 0};
+        if (m < p.M && col_ok) v = *(const i32x4_t*)(p.aux_in + (size_t)m * p.ldx + nw + sch * 8);
+        *(i32x4_t*)(patch + r * PITCH + sch * 16) = v;
+      }
+    }
+    // ---- (B) bias, derivative / pre-activation ----
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int n = nw + i * 16 + g * 4;
+      f32x4_t bv = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      if (p.bias && n < p.N) bv = *(const f32x4_t*)(p.bias + n);
+#pragma unroll
+      for (int jl = 0; jl < 4; ++jl) {
+        f32x4_t v = acc[i][jg * 4 + jl] + bv;
+        if (act == LC2IS_ACT_DQUICK_GELU || act == LC2IS_ACT_DRELU) {
+          const i32x2_t zk = *(const i32x2_t*)(patch + (jl * 16 + frow) * PITCH + (i * 16 + g * 4) * 2);
+          float z[4] = {bf16_to_f32((bf16_t)(zk[0] & 0xffff)), bf16_to_f32((bf16_t)((unsigned)zk[0] >> 16)),
+                        bf16_to_f32((bf16_t)(zk[1] & 0xffff)), bf16_to_f32((bf16_t)((unsigned)zk[1] >> 16))};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (act == LC2IS_ACT_DRELU) {
+              v[r] = z[r] > 0.f ? v[r] : 0.f;
+            } else {
+              const float sg = sigmoidf_fast(1.702f * z[r]);
+              v[r] *= sg * (1.f + 1.702f * z[r] * (1.f - sg));
+            }
+          }
+        }
+        acc[i][jg * 4 + jl] = v;
+      }
+    }
+    // ---- (C) store the pre-activation (bf16) ----
+    if ((act == LC2IS_ACT_QUICK_GELU || act == LC2IS_ACT_RELU) && p.aux_out) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int jl = 0; jl < 4; ++jl) {
+          const f32x4_t v = acc[i][jg * 4 + jl];
+          i32x2_t pk = {(int)pack_bf16x2(v[0], v[1]), (int)pack_bf16x2(v[2], v[3])};
+          *(i32x2_t*)(patch + (jl * 16 + frow) * PITCH + (i * 16 + g * 4) * 2) = pk;
+        }
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int r = it * 8 + srow, m = mrow0 + r;
+        const i32x4_t v = *(const i32x4_t*)(patch + r * PITCH + sch * 16);
+        if (m < p.M && col_ok) *(i32x4_t*)(p.aux_out + (size_t)m * p.ldy + nw + sch * 8) = v;
+      }
+    }
+    // ---- (D) activation, fp32 residual / output (direct), (E) bf16 output through the patch ----
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int n = nw + i * 16 + g * 4;
+#pragma unroll
+      for (int jl = 0; jl < 4; ++jl) {
+        const int m = mrow0 + jl * 16 + frow;
+        f32x4_t v = acc[i][jg * 4 + jl];
+        if (act == LC2IS_ACT_QUICK_GELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = v[r] * sigmoidf_fast(1.702f * v[r]);
+        } else if (act == LC2IS_ACT_RELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        const bool ok = (m < p.M) && (n < p.N);
+        if (p.resid && ok) v += *(const f32x4_t*)(p.resid + (size_t)m * p.ldr + n);
+        if (p.out_f32 && ok) *(f32x4_t*)(p.out_f32 + (size_t)m * p.ldf + n) = v;
+        if (p.out_bf16) {
+          i32x2_t pk = {(int)pack_bf16x2(v[0], v[1]), (int)pack_bf16x2(v[2], v[3])};
+          *(i32x2_t*)(patch + (jl * 16 + frow) * PITCH + (i * 16 + g * 4) * 2) = pk;
+        }
+      }
+    }
+    if (p.out_bf16) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int r = it * 8 + srow, m = mrow0 + r;
+        const i32x4_t v = *(const i32x4_t*)(patch + r * PITCH + sch * 16);
+        if (m < p.M && col_ok) *(i32x4_t*)(p.out_bf16 + (size_t)m * p.ldo + nw + sch * 8) = v;
+      }
+    }
+  }
+}
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmNtArgs p) {
@@ -130,49 +289,103 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmNtAr
     __syncthreads();
   }
 
-  // ---- epilogue: lane holds C[m][n..n+3], n = 4*(lane>>4) within the 16-wide sub-tile ----
-  const int act = p.act;
+  gemm_epilogue<TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lane);
+}
+
+template <int BM, int A_PIECES, int W_PIECES>
+__device__ __forceinline__ void dma_stage(__amdgpu_buffer_rsrc_t rsA, __amdgpu_buffer_rsrc_t rsW, char* buf, int wid,
+                                          const int (&a_goff)[A_PIECES], const int (&w_goff)[W_PIECES], int kb) {
 #pragma unroll
-  for (int i = 0; i < TN; ++i) {
-    const int n = n0 + wn * WN + i * 16 + g * 4;
-    if (n >= p.N) continue;
-    f32x4_t bv = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    if (p.bias) bv = *(const f32x4_t*)(p.bias + n);
+  for (int j = 0; j < A_PIECES; ++j)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(buf + (wid * A_PIECES + j) * 1024), 16, a_goff[j] + kb, 0,
+                                             0, 0);
 #pragma unroll
-    for (int j = 0; j < TM; ++j) {
-      const int m = m0 + wm * WM + j * 16 + frow;
-      if (m >= p.M) continue;
-      f32x4_t v = acc[i][j] + bv;
-      if (act == LC2IS_ACT_QUICK_GELU || act == LC2IS_ACT_RELU) {
-        if (p.aux_out) {
-          i32x2_t pk = {(int)pack_bf16x2(v[0], v[1]), (int)pack_bf16x2(v[2], v[3])};
-          *(i32x2_t*)(p.aux_out + (size_t)m * p.ldy + n) = pk;
-        }
+  for (int j = 0; j < W_PIECES; ++j)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_PTR(buf + BM * 128 + (wid * W_PIECES + j) * 1024), 16,
+                                             w_goff[j] + kb, 0, 0, 0);
+}
+
+// ---- LDS-DMA variant for large problems ------------------------------------------------------------------
+// Same tile algebra, but the K tiles go global -> LDS directly (buffer_load_dwordx4 ... lds, range-checked):
+// no staging VGPRs, no ds_write pass.  An LDS-DMA wave instruction writes 64 x 16 B = 8 rows of 128 B
+// linearly, so the XOR swizzle is applied on the per-lane SOURCE address (lane l fetches chunk (l&7)^(l>>3) of
+// row l>>3) and the fragment reads use the same involution.  The DMA of tile t+1 is issued right after the
+// barrier that publishes tile t and flies during the MFMAs of tile t; the barrier's implicit vmcnt(0) retires
+// it.  256x256 tile, 8 waves (2x4), 128x64 per wave: 12 ds_read_b128 per 32 MFMAs.
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_dma_kernel(GemmNtArgs p) {
+  constexpr int NWAVE = WAVES_M * WAVES_N;
+  constexpr int BK = 64;
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int TM = WM / 16, TN = WN / 16;
+  constexpr int A_PIECES = BM / 8 / NWAVE;  // 1-KiB pieces (8 rows) of the X tile per wave
+  constexpr int W_PIECES = BN / 8 / NWAVE;
+  constexpr int STAGE = (BM + BN) * 128;
+  static_assert(BM % (8 * NWAVE) == 0 && BN % (8 * NWAVE) == 0, "tile/waves mismatch");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+  const int ntn = (p.N + BN - 1) / BN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+
+  const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, (unsigned)p.M * (unsigned)p.lda * 2u);
+  const __amdgpu_buffer_rsrc_t rsW = make_rsrc(p.W, (unsigned)p.N * (unsigned)p.ldw * 2u);
+
+  // per-lane source offsets of this wave's pieces (piece j of wave w = rows 8*(w*PIECES + j) .. +7)
+  const int lrow = lane >> 3, lch = (lane & 7) ^ (lane >> 3);
+  int a_goff[A_PIECES], w_goff[W_PIECES];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          v[r] = (act == LC2IS_ACT_RELU) ? fmaxf(v[r], 0.f) : v[r] * sigmoidf_fast(1.702f * v[r]);
-      } else if (act == LC2IS_ACT_DQUICK_GELU || act == LC2IS_ACT_DRELU) {
-        const i32x2_t zk = *(const i32x2_t*)(p.aux_in + (size_t)m * p.ldx + n);
-        float z[4] = {bf16_to_f32((bf16_t)(zk[0] & 0xffff)), bf16_to_f32((bf16_t)((unsigned)zk[0] >> 16)),
-                      bf16_to_f32((bf16_t)(zk[1] & 0xffff)), bf16_to_f32((bf16_t)((unsigned)zk[1] >> 16))};
+  for (int j = 0; j < A_PIECES; ++j)
+    a_goff[j] = ((m0 + 8 * (wid * A_PIECES + j) + lrow) * p.lda + lch * 8) * 2;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (act == LC2IS_ACT_DRELU) {
-            v[r] = z[r] > 0.f ? v[r] : 0.f;
-          } else {
-            const float s = sigmoidf_fast(1.702f * z[r]);
-            v[r] *= s * (1.f + 1.702f * z[r] * (1.f - s));
-          }
-        }
-      }
-      if (p.resid) v += *(const f32x4_t*)(p.resid + (size_t)m * p.ldr + n);
-      if (p.out_f32) *(f32x4_t*)(p.out_f32 + (size_t)m * p.ldf + n) = v;
-      if (p.out_bf16) {
-        i32x2_t pk = {(int)pack_bf16x2(v[0], v[1]), (int)pack_bf16x2(v[2], v[3])};
-        *(i32x2_t*)(p.out_bf16 + (size_t)m * p.ldo + n) = pk;
-      }
+  for (int j = 0; j < W_PIECES; ++j)
+    w_goff[j] = ((n0 + 8 * (wid * W_PIECES + j) + lrow) * p.ldw + lch * 8) * 2;
+
+
+  f32x4_t acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, g = lane >> 4, sw = lane & 7;
+  const int x_frag = (wm * WM + frow) * 128;
+  const int w_frag = BM * 128 + (wn * WN + frow) * 128;
+  const int kc_off0 = ((0 + g) ^ sw) << 4, kc_off1 = ((4 + g) ^ sw) << 4;
+  const int nk = p.K / BK;
+
+  dma_stage<BM, A_PIECES, W_PIECES>(rsA, rsW, smem, wid, a_goff, w_goff, 0);
+  __syncthreads();  // emits s_waitcnt vmcnt(0): tile 0 has landed for every wave
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* cur = smem + (kt & 1) * STAGE;
+    if (kt + 1 < nk)
+      dma_stage<BM, A_PIECES, W_PIECES>(rsA, rsW, smem + ((kt + 1) & 1) * STAGE, wid, a_goff, w_goff,
+                                        (kt + 1) * BK * 2);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int ko = ks ? kc_off1 : kc_off0;
+      bf16x8_t xf[TM], wf[TN];
+#pragma unroll
+      for (int j = 0; j < TM; ++j) xf[j] = *(const bf16x8_t*)(cur + x_frag + j * 16 * 128 + ko);
+#pragma unroll
+      for (int i = 0; i < TN; ++i) wf[i] = *(const bf16x8_t*)(cur + w_frag + i * 16 * 128 + ko);
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
     }
+    __syncthreads();  // all reads of `cur` done; DMA of the next tile retired (vmcnt(0)) and published
   }
+  if (p.staged_epi)
+    gemm_epilogue_lds<TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lane, wid, smem);
+  else
+    gemm_epilogue<TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lane);
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
@@ -181,6 +394,22 @@ int launch_cfg(const GemmNtArgs& a, hipStream_t stream) {
   constexpr int LDS = 2 * (BM + BN) * 128;
   auto kern = gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N>;
   static bool attr_set = false;  // idempotent; a race only repeats the same call
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+      return LC2IS_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
+  hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(NT), LDS, stream, a);
+  return lc2is_check_launch();
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+int launch_dma(const GemmNtArgs& a, hipStream_t stream) {
+  constexpr int NT = WAVES_M * WAVES_N * 64;
+  constexpr int LDS = 2 * (BM + BN) * 128;
+  auto kern = gemm_nt_dma_kernel<BM, BN, WAVES_M, WAVES_N>;
+  static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
       return LC2IS_ERR_LAUNCH;
@@ -212,11 +441,14 @@ extern "C" int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw
   if ((double)(M + 256) * lda * 2.0 >= 2147483648.0 || (double)(N + 256) * ldw * 2.0 >= 2147483648.0)
     return LC2IS_ERR_UNSUPPORTED;
   GemmNtArgs a{(const bf16_t*)A, lda, (const bf16_t*)W, ldw, bias, resid, ldr, (const bf16_t*)aux_in, ldx,
-               (bf16_t*)out_bf16, ldo, out_f32, ldf, (bf16_t*)aux_out, ldy, M, N, K, act};
+               (bf16_t*)out_bf16, ldo, out_f32, ldf, (bf16_t*)aux_out, ldy, M, N, K, act, 0};
+  a.staged_epi = (N % 8 == 0) && (!out_bf16 || ldo % 8 == 0) && (!aux_out || ldy % 8 == 0) &&
+                 (!aux_in || ldx % 8 == 0) && (out_bf16 || aux_out || aux_in);
   int cfg = tile_cfg;
   if (cfg == 0) {
     const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-    if (tiles128 >= 1024 && N % 128 == 0) cfg = 2;       // plenty of work: 256x128 halves W re-reads
+    if (tiles128 >= 1024 && N % 256 == 0) cfg = 4;       // plenty of work: 256x256 LDS-DMA tiles
+    else if (tiles128 >= 512) cfg = 6;                   // 128x128 LDS-DMA tiles, 2 blocks/CU
     else if (tiles128 >= 128) cfg = 1;
     else cfg = 3;                                        // small problem: 64x64 tiles to fill the chip
   }
@@ -224,6 +456,9 @@ extern "C" int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw
     case 1: return launch_cfg<128, 128, 2, 2>(a, stream);
     case 2: return launch_cfg<256, 128, 4, 2>(a, stream);
     case 3: return launch_cfg<64, 64, 2, 2>(a, stream);
+    case 4: return launch_dma<256, 256, 2, 4>(a, stream);
+    case 5: return launch_dma<256, 128, 4, 2>(a, stream);
+    case 6: return launch_dma<128, 128, 2, 2>(a, stream);
     default: return LC2IS_ERR_UNSUPPORTED;
   }
 }

@@ -15,7 +15,8 @@ def _rel(a, b):
 
 @pytest.mark.parametrize("M,N,K,cfg", [
     (300, 192, 128, 1), (300, 192, 128, 2), (300, 192, 128, 3), (1025, 768, 768, 0), (4100, 2304, 768, 0),
-    (129, 152, 512, 0), (77, 64, 64, 3), (2050, 768, 3072, 2),
+    (129, 152, 512, 0), (77, 64, 64, 3), (2050, 768, 3072, 2), (2050, 768, 3072, 4), (300, 192, 128, 4),
+    (1025, 2304, 768, 5), (300, 192, 128, 5), (515, 384, 192, 6), (4100, 768, 768, 4),
 ])
 def test_gemm_nt_plain(dev, M, N, K, cfg):
     from lc2is_amd import ops
@@ -40,8 +41,9 @@ def test_gemm_nt_asymmetric_identity(dev):
     assert torch.equal(of, w.float().T.contiguous())
 
 
+@pytest.mark.parametrize("cfg", [0, 4, 5, 6])
 @pytest.mark.parametrize("act", ["quick_gelu", "relu"])
-def test_gemm_nt_activation_and_backward_epilogue(dev, act):
+def test_gemm_nt_activation_and_backward_epilogue(dev, act, cfg):
     from lc2is_amd import ops
     g = torch.Generator(device="cpu").manual_seed(5)
     M, N, K = 515, 384, 192
@@ -50,16 +52,17 @@ def test_gemm_nt_activation_and_backward_epilogue(dev, act):
     bias = torch.randn(N, generator=g).to(dev)
     resid = torch.randn(M, N, generator=g).to(dev)
     code = ops.ACT_QUICK_GELU if act == "quick_gelu" else ops.ACT_RELU
-    ob, of, z = ops.gemm_nt(a, w, bias, act=code, resid=resid, out_bf16=True, out_f32=True, aux_out=True)
+    ob, of, z = ops.gemm_nt(a, w, bias, act=code, resid=resid, out_bf16=True, out_f32=True, aux_out=True, tile_cfg=cfg)
     zr = a.double() @ w.double().T + bias.double()
     ar = zr * torch.sigmoid(1.702 * zr) if act == "quick_gelu" else zr.clamp_min(0)
     assert _rel(z.float(), zr) < 4e-3
     assert _rel(of, ar + resid.double()) < 1e-5
+    assert _rel(ob.float(), ar + resid.double()) < 4e-3
     # backward epilogue: dz = (dy @ w2) * act'(saved)
     dy = _bf(torch.randn(M, K, generator=g)).to(dev)
     saved = z if act == "quick_gelu" else ob  # relu saves its output
     dcode = ops.ACT_DQUICK_GELU if act == "quick_gelu" else ops.ACT_DRELU
-    dz, _, _ = ops.gemm_nt(dy, w, None, act=dcode, aux_in=saved)
+    dz, _, _ = ops.gemm_nt(dy, w, None, act=dcode, aux_in=saved, tile_cfg=cfg)
     s = saved.double()
     if act == "quick_gelu":
         sg = torch.sigmoid(1.702 * s)
