@@ -1,0 +1,75 @@
+"""Data-parallel wiring on the GPU box: two ranks share the one GPU over gloo (RCCL needs one device per rank;
+the 8-GPU run is the driver's) — checks that the per-module reduction callbacks, arena ranges and the fused
+optimizer keep both replicas identical and that the reduced gradient equals the single-process global-batch one."""
+import os
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+G = ROOT / "tests" / "golden"
+
+
+def _build(dev):
+    import lc2is_amd.nn as N
+    fx = torch.load(G / "base_tiny.pt", weights_only=True)
+    m = N.BaseModelWithText(16, 64, 16, vision_arch=N.ClipArch(128, 2, 2, 256),
+                            text_arch=N.ClipArch(64, 1, 2, 128, vocab=512, eos_token_id=511), nhead=2,
+                            dim_feedforward=128, out_dim=64)
+    m.load_state_dict(fx["state_dict"], strict=True)
+    return m.to(dev).train(), fx
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    from lc2is_amd.dp import GradReducer
+    from lc2is_amd.step import TrainStep
+    m, fx = _build(dev)
+    red = GradReducer()
+    ts = TrainStep(m, optimizer="sgd", lr=0.05, reducer=red)
+    red.broadcast_params(ts.arena.flat, src=0)
+    inputs = {k: fx[k][rank:rank + 1].to(dev) for k in ("pixel_values", "input_ids", "attention_mask")}
+    labels = fx["labels"][rank:rank + 1].to(dev)
+    loss = ts.step(inputs, labels)
+    torch.cuda.synchronize()
+    torch.save(dict(rank=rank, loss=float(loss.item()), flat=ts.arena.flat.cpu(), grad=(ts.arena.grad / world).cpu()),
+               os.path.join(q, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_matches_global_batch(dev, tmp_path):
+    ctx = mp.get_context("spawn")
+    port = 29700 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    r0 = torch.load(tmp_path / "rank0.pt", weights_only=True)
+    r1 = torch.load(tmp_path / "rank1.pt", weights_only=True)
+    l0, p0, g0, l1, p1, g1 = r0["loss"], r0["flat"], r0["grad"], r1["loss"], r1["flat"], r1["grad"]
+    assert torch.equal(p0, p1), "replicas diverged after one DP step"
+    assert torch.equal(g0, g1)
+    # single process on the global batch of 2
+    from lc2is_amd.step import TrainStep
+    m, fx = _build(dev)
+    ts = TrainStep(m, optimizer="sgd", lr=0.05)
+    inputs = {k: fx[k].to(dev) for k in ("pixel_values", "input_ids", "attention_mask")}
+    loss = ts.step(inputs, fx["labels"].to(dev))
+    assert abs(loss.item() - 0.5 * (l0 + l1)) < 1e-3
+    gref = ts.arena.grad.cpu()
+    rel = ((g0 - gref).norm() / gref.norm()).item()
+    assert rel < 2e-2, rel   # different batch split -> different bf16 rounding, same gradient
+    relp = ((p0 - ts.arena.flat.cpu()).norm() / (0.05 * gref.norm())).item()
+    assert relp < 2e-2, relp
