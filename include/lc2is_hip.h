@@ -65,10 +65,11 @@ int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw, const flo
 /* dW[N,K] (fp32) = dY[M,N]^T · X[M,K]  (weight gradient of out = X·W^T), reduced over M.
  * The M range is cut into `splits` slabs (workspace = splits*N*K fp32) summed by a second launch, so
  * the result is bitwise reproducible.  accumulate != 0 adds into dW instead of overwriting.
+ * db (optional, fp32 [N]): the bias gradient colsum(dY), fused (one extra ones-fragment MFMA per tile).
  * N % 8 == 0 and K % 8 == 0.   replaces: autograd of the nn.Linear calls above. */
 size_t lc2is_gemm_tn_workspace_bytes(int M, int N, int K);
-int lc2is_gemm_tn_bf16(const void* dY, int ldy, const void* X, int ldx, float* dW, int ldw, int M, int N,
-                       int K, int accumulate, void* workspace, size_t workspace_bytes,
+int lc2is_gemm_tn_bf16(const void* dY, int ldy, const void* X, int ldx, float* dW, int ldw, float* db, int M,
+                       int N, int K, int accumulate, void* workspace, size_t workspace_bytes,
                        lc2is_stream_t stream);
 
 /* db[N] (fp32) = column sums of dY[M,N] (bias gradient). workspace >= lc2is_colsum_workspace_bytes. */

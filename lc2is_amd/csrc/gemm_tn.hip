@@ -12,6 +12,7 @@
 // fp32 slab and a second launch sums the slabs in a fixed order (bitwise reproducible, no atomics).
 #include "common.h"
 #include "lc2is_hip.h"
+#include <type_traits>
 
 namespace {
 
@@ -55,7 +56,8 @@ __device__ __forceinline__ bf16x8_t tr_frag(const char* tile, int addr_lo, int a
 
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__ dY, int ldy,
                                                        const bf16_t* __restrict__ X, int ldx, float* out,
-                                                       int ldo, size_t split_stride, int M, int N, int K,
+                                                       int ldo, size_t split_stride, float* bias_out,
+                                                       size_t bias_split_stride, int M, int N, int K,
                                                        int ntn, int ntk, int chunk, int accumulate) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -110,6 +112,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  // fused bias gradient: db[n] = sum_m dY[m][n] = (ones^T · dY), one extra MFMA per n sub-tile with an all-ones
+  // A fragment, on the dY fragments already in registers; only the k-tile-0 blocks' wk == 0 waves do it
+  const bool do_cs = (bias_out != nullptr) && (tile % ntk == 0) && (wk == 0);
+  f32x4_t cs[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) cs[b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const s16x8_t ones_s = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_s);
 
   i32x4_t ry[4], rx[4];
   auto gload = [&](int step) {
@@ -134,30 +144,49 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
   }
   __syncthreads();
 
-  for (int st = 0; st < nsteps; ++st) {
-    const char* cur = smem + (st & 1) * TN_STAGE;
-    char* nxt = smem + ((st + 1) & 1) * TN_STAGE;
-    const bool more = (st + 1) < nsteps;
-    if (more) gload(st + 1);
+  // the loop is instantiated twice (hand-unswitched on do_cs) so the common path carries no branch
+  auto mainloop = [&](auto cs_tag) {
+    constexpr bool CS = decltype(cs_tag)::value;
+    for (int st = 0; st < nsteps; ++st) {
+      const char* cur = smem + (st & 1) * TN_STAGE;
+      char* nxt = smem + ((st + 1) & 1) * TN_STAGE;
+      const bool more = (st + 1) < nsteps;
+      if (more) gload(st + 1);
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      bf16x8_t xf[4], yf[4];
+      for (int s = 0; s < 2; ++s) {
+        bf16x8_t xf[4], yf[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        yf[t] = tr_frag(cur, ya_lo[s][t], ya_hi[s][t]);
-        xf[t] = tr_frag(cur + TN_TILE_BYTES, xa_lo[s][t], xa_hi[s][t]);
+        for (int t = 0; t < 4; ++t) {
+          yf[t] = tr_frag(cur, ya_lo[s][t], ya_hi[s][t]);
+          xf[t] = tr_frag(cur + TN_TILE_BYTES, xa_lo[s][t], xa_hi[s][t]);
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[a], yf[b], acc[a][b], 0, 0, 0);
+        if constexpr (CS) {
+#pragma unroll
+          for (int b = 0; b < 4; ++b) cs[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, yf[b], cs[b], 0, 0, 0);
+        }
       }
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[a], yf[b], acc[a][b], 0, 0, 0);
+      if (more) lstore(nxt);
+      __syncthreads();
     }
-    if (more) lstore(nxt);
-    __syncthreads();
-  }
+  };
+  if (do_cs) mainloop(std::true_type{}); else mainloop(std::false_type{});
 
   float* o = out + (size_t)split * split_stride;
+  if (do_cs && lane < 16) {  // every row of cs[b] holds the column sums; lanes 0..15, register 0 = row 0
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int n = n0 + wn * 64 + b * 16 + lane;
+      if (n < N) {
+        float* dst = bias_out + (size_t)split * bias_split_stride + n;
+        *dst = (accumulate ? *dst : 0.f) + cs[b][0];
+      }
+    }
+  }
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
     const int n = n0 + wn * 64 + b * 16 + (lane & 15);
@@ -245,11 +274,11 @@ inline int colsum_parts(int M) {
 extern "C" size_t lc2is_gemm_tn_workspace_bytes(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   const TnPlan p = tn_plan(M, N, K);
-  return p.splits > 1 ? (size_t)p.splits * N * K * sizeof(float) : 0;
+  return p.splits > 1 ? (size_t)p.splits * N * ((size_t)K + 1) * sizeof(float) : 0;
 }
 
-extern "C" int lc2is_gemm_tn_bf16(const void* dY, int ldy, const void* X, int ldx, float* dW, int ldw, int M,
-                                  int N, int K, int accumulate, void* workspace, size_t workspace_bytes,
+extern "C" int lc2is_gemm_tn_bf16(const void* dY, int ldy, const void* X, int ldx, float* dW, int ldw, float* db,
+                                  int M, int N, int K, int accumulate, void* workspace, size_t workspace_bytes,
                                   lc2is_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!dY || !X || !dW) return LC2IS_ERR_NULL;
@@ -270,14 +299,22 @@ extern "C" int lc2is_gemm_tn_bf16(const void* dY, int ldy, const void* X, int ld
   const int grid = p.ntn * p.ntk * p.splits;
   if (p.splits == 1) {
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(grid), dim3(256), 2 * TN_STAGE, stream, (const bf16_t*)dY, ldy,
-                       (const bf16_t*)X, ldx, dW, ldw, (size_t)0, M, N, K, p.ntn, p.ntk, p.chunk, accumulate);
+                       (const bf16_t*)X, ldx, dW, ldw, (size_t)0, db, (size_t)0, M, N, K, p.ntn, p.ntk, p.chunk,
+                       accumulate);
     return lc2is_check_launch();
   }
+  float* bias_ws = db ? (float*)workspace + (size_t)p.splits * N * K : nullptr;
   hipLaunchKernelGGL(gemm_tn_kernel, dim3(grid), dim3(256), 2 * TN_STAGE, stream, (const bf16_t*)dY, ldy,
-                     (const bf16_t*)X, ldx, (float*)workspace, K, (size_t)N * K, M, N, K, p.ntn, p.ntk,
-                     p.chunk, 0);
+                     (const bf16_t*)X, ldx, (float*)workspace, K, (size_t)N * K, bias_ws, (size_t)N, M, N, K,
+                     p.ntn, p.ntk, p.chunk, 0);
   int rc = lc2is_check_launch();
   if (rc) return rc;
+  if (db) {
+    hipLaunchKernelGGL(partials_reduce_kernel, dim3((N + 63) / 64, 1), dim3(1024), 0, stream,
+                       (const float*)bias_ws, p.splits, (size_t)N, (size_t)0, N, db, (float*)nullptr, accumulate);
+    rc = lc2is_check_launch();
+    if (rc) return rc;
+  }
   const size_t total4 = (size_t)N * K / 4;
   int rgrid = (int)((total4 + 255) / 256);
   if (rgrid > 2048) rgrid = 2048;

@@ -91,10 +91,17 @@ def grad_buf(p: torch.Tensor):
 
 def linear_bwd_params(dy_bf16: torch.Tensor, x_bf16: torch.Tensor, weight: nn.Parameter, bias: nn.Parameter | None):
     """dW = dy^T x, db = colsum(dy), written into the parameters' gradient buffers."""
+    want_b = bias is not None and bias.requires_grad
     if weight.requires_grad:
         g, acc = grad_buf(weight)
-        ops.gemm_tn(dy_bf16, x_bf16, g.reshape(g.shape[0], -1), accumulate=acc)
-    if bias is not None and bias.requires_grad:
+        gb = None
+        if want_b:
+            gb, accb = grad_buf(bias)
+            if accb != acc:      # mixed gradient state: fall back to the separate column-sum launch
+                ops.colsum(dy_bf16, gb, accumulate=accb)
+                gb = None
+        ops.gemm_tn(dy_bf16, x_bf16, g.reshape(g.shape[0], -1), accumulate=acc, db=gb)
+    elif want_b:
         g, acc = grad_buf(bias)
         ops.colsum(dy_bf16, g, accumulate=acc)
 

@@ -19,7 +19,7 @@ _P, _I, _F, _Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 _ARGTYPES = {
     "lc2is_gemm_nt_bf16": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "lc2is_gemm_tn_workspace_bytes": [_I, _I, _I],
-    "lc2is_gemm_tn_bf16": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P, _Z, _P],
+    "lc2is_gemm_tn_bf16": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _Z, _P],
     "lc2is_colsum_workspace_bytes": [_I, _I],
     "lc2is_colsum_bf16": [_P, _I, _P, _I, _I, _I, _P, _Z, _P],
     "lc2is_layernorm_fwd": [_P, _I, _P, _P, _P, _I, _P, _I, _P, _P, _I, _I, _F, _P],
@@ -132,8 +132,9 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None, 
     return ob, of, ao
 
 
-def gemm_tn(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor | None = None, accumulate: bool = False):
-    """dw[N,K] (fp32) = dy[M,N]^T @ x[M,K]."""
+def gemm_tn(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor | None = None, accumulate: bool = False,
+            db: torch.Tensor | None = None):
+    """dw[N,K] (fp32) = dy[M,N]^T @ x[M,K]; optional fused bias gradient db[N] = dy.sum(0) (same accumulate flag)."""
     _chk(dy, torch.bfloat16, "dy"); _chk(x, torch.bfloat16, "x")
     M, N = dy.shape
     M2, K = x.shape
@@ -142,10 +143,12 @@ def gemm_tn(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor | None = None, a
     if dw is None:
         dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
         accumulate = False
-    _chk(dw, torch.float32, "dw")
+    _chk(dw, torch.float32, "dw"); _chk(db, torch.float32, "db", 1)
+    if db is not None and db.numel() != N:
+        raise RuntimeError("lc2is_amd.gemm_tn: db length != N")
     nbytes = _fn("lc2is_gemm_tn_workspace_bytes")(M, N, K)
     ws = workspace(nbytes, dy.device, "gemm_tn")
-    rc = _fn("lc2is_gemm_tn_bf16")(_ptr(dy), _ld(dy), _ptr(x), _ld(x), _ptr(dw), _ld(dw), M, N, K,
+    rc = _fn("lc2is_gemm_tn_bf16")(_ptr(dy), _ld(dy), _ptr(x), _ld(x), _ptr(dw), _ld(dw), _ptr(db), M, N, K,
                                    int(accumulate), _ptr(ws), ws.numel(), _stream())
     _lib.check(rc, f"gemm_tn M={M} N={N} K={K}")
     return dw

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_workspace_size_queries_are_pure_host_functions():
     from lc2is_amd import ops
-    assert ops._fn("lc2is_gemm_tn_workspace_bytes")(32800, 3072, 768) > 0
+    assert ops._fn("lc2is_gemm_tn_workspace_bytes")(32800, 3072, 768) == 7 * 3072 * 769 * 4
     assert ops._fn("lc2is_gemm_tn_workspace_bytes")(64, 64, 64) == 0
     assert ops._fn("lc2is_colsum_workspace_bytes")(100, 64) == 25 * 64 * 4
     assert ops._fn("lc2is_layernorm_bwd_workspace_bytes")(10, 64) == 3 * 2 * 64 * 4

@@ -87,6 +87,13 @@ def test_gemm_tn(dev, M, N, K):
     assert _rel(dw2, 2 * ref) < 1e-5
     # bitwise reproducible
     assert torch.equal(ops.gemm_tn(dy, x), dw)
+    # fused bias gradient
+    db = torch.full((N,), 7.0, device=dev)
+    dw3 = ops.gemm_tn(dy, x, torch.empty_like(dw), db=db)
+    assert torch.equal(dw3, dw) and _rel(db, dy.double().sum(0)) < 1e-5
+    db2 = db.clone()
+    ops.gemm_tn(dy, x, dw3, accumulate=True, db=db2)
+    assert _rel(db2, 2 * dy.double().sum(0)) < 1e-5
 
 
 def test_gemm_tn_asymmetric(dev):

@@ -54,6 +54,9 @@ def main():
         dw = torch.empty(N, K, device=dev)
         t = timeit(lambda: ops.gemm_tn(dy, a, dw))
         print(f"gemm_tn      M={M} N={N} K={K}: {t*1e6:8.1f} us  {2*M*N*K/t/1e12:7.1f} TF/s", flush=True)
+        dbv = torch.empty(N, device=dev)
+        t = timeit(lambda: ops.gemm_tn(dy, a, dw, db=dbv))
+        print(f"gemm_tn+db   M={M} N={N} K={K}: {t*1e6:8.1f} us  {2*M*N*K/t/1e12:7.1f} TF/s", flush=True)
         t = timeit(lambda: ops.colsum(dy))
         print(f"colsum       M={M} N={N}: {t*1e6:8.1f} us  {M*N*2/t/1e9:7.1f} GB/s", flush=True)
     x = torch.randn(M, 768, device=dev)
