@@ -84,7 +84,7 @@ __device__ __forceinline__ float dot8(const i32x4_t& a, const i32x4_t& b) {
 // (1) dQ kernel: grid (ceil(Sq/128), H, B), 4 waves x 32 queries; loops over 64-key tiles.
 // ------------------------------------------------------------------------------------------------------
 template <int D>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs p) {
+__global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dq_kernel(AttnBwdArgs p) {
   using I = Img<D>;
   constexpr int NKS = D / 16, NDT = D / 32, CH = I::CH, NCH = I::NCH;
   constexpr int STAGE = 2 * I::TILE + 256;  // K image, V image, 64 bias floats
@@ -167,6 +167,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs p) {
   };
 
   const int q4 = (lane >> 2) & 3, p4 = lane & 3, cg = (lane >> 4) & 1;
+  // LDS addresses are hoisted out of the key loop: the swizzle only looks at row bits 0..3, so adding 16/32-row
+  // steps is a compile-time immediate on top of these per-lane bases (the XOR itself is not additive).
+  int row_addr[NKS], tr_lo[NDT], tr_hi[NDT];
+#pragma unroll
+  for (int s = 0; s < NKS; ++s) row_addr[s] = I::off(l31, 2 * s + hh);
+#pragma unroll
+  for (int d = 0; d < NDT; ++d) {
+    const int e = 32 * d + 16 * cg + 4 * p4;
+    tr_lo[d] = I::off(4 * hh + q4, e >> 3) + (e & 7) * 2;
+    tr_hi[d] = I::off(4 * hh + q4 + 8, e >> 3) + (e & 7) * 2;
+  }
 
   f32x16_t dq[NDT];
 #pragma unroll
@@ -187,6 +198,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs p) {
     if (more) gload(kt + 1);
     const float* biasv = (const float*)(cur + 2 * I::TILE);
     const bool diag = p.causal && (kt * 64 + 63 > blockIdx.x * 128);
+    const bool masked = diag || (kt * 64 + 64 > p.Sk) || (p.kbias != nullptr);
 
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -195,36 +207,42 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs p) {
       for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
 #pragma unroll
       for (int s = 0; s < NKS; ++s) {
-        const int a = I::off(32 * t + l31, 2 * s + hh);
+        const int a = row_addr[s] + 32 * t * I::PITCH;
         const bf16x8_t kf = *(const bf16x8_t*)(cur + a);
         const bf16x8_t vf = *(const bf16x8_t*)(cur + I::TILE + a);
         st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st, 0, 0, 0);
         dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[s], dpt, 0, 0, 0);
       }
+      if (!masked) {  // interior tile: one fma + exp + sub + mul per score, no branches
+        const float neg_lse = -lse;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const f32x4_t bz = *(const f32x4_t*)(biasv + 32 * t + 8 * c + 4 * hh);
+        for (int r = 0; r < 16; ++r) {
+          const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], p.scale_log2, neg_lse));
+          dpt[r] = pr * (dpt[r] - delta);
+        }
+      } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float s2 = st[4 * c + j] * p.scale_log2 + bz[j] - lse;
-          if (diag) {
-            const int key = kt * 64 + 32 * t + 8 * c + 4 * hh + j;
-            if (key > qrow) s2 = -INF;
+        for (int c = 0; c < 4; ++c) {
+          const f32x4_t bz = *(const f32x4_t*)(biasv + 32 * t + 8 * c + 4 * hh);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float s2 = st[4 * c + j] * p.scale_log2 + bz[j] - lse;
+            if (diag) {
+              const int key = kt * 64 + 32 * t + 8 * c + 4 * hh + j;
+              if (key > qrow) s2 = -INF;
+            }
+            const float pr = __builtin_amdgcn_exp2f(s2);
+            dpt[4 * c + j] = pr * (dpt[4 * c + j] - delta);
           }
-          const float pr = __builtin_amdgcn_exp2f(s2);
-          dpt[4 * c + j] = pr * (dpt[4 * c + j] - delta);
         }
       }
 #pragma unroll
       for (int s2i = 0; s2i < 2; ++s2i) {
         const bf16x8_t dsf = pack8(dpt, 8 * s2i);
-        const int krow = 32 * t + 16 * s2i + 4 * hh + q4;
+        const int roff = (32 * t + 16 * s2i) * I::PITCH;
 #pragma unroll
         for (int d = 0; d < NDT; ++d) {
-          const int e = 32 * d + 16 * cg + 4 * p4;  // element column
-          const int lo = I::off(krow, e >> 3) + (e & 7) * 2;
-          const int hi = I::off(krow + 8, e >> 3) + (e & 7) * 2;
-          const bf16x8_t ktf = tr_frag3(cur, lo, hi);
+          const bf16x8_t ktf = tr_frag3(cur, tr_lo[d] + roff, tr_hi[d] + roff);
           dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf, dq[d], 0, 0, 0);
         }
       }
@@ -251,7 +269,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs p) {
 // (2) dK/dV kernel: grid (ceil(Sk/128), H, B), 4 waves x 32 keys; loops over 64-query tiles.
 // ------------------------------------------------------------------------------------------------------
 template <int D>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
+__global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
   using I = Img<D>;
   constexpr int NKS = D / 16, NDT = D / 32, CH = I::CH, NCH = I::NCH;
   constexpr int STAGE = 2 * I::TILE + 512;  // Q image, dO image, 64 lse2, 64 delta
@@ -322,6 +340,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
   };
 
   const int q4 = (lane >> 2) & 3, p4 = lane & 3, cg = (lane >> 4) & 1;
+  int row_addr[NKS], tr_lo[NDT], tr_hi[NDT];  // hoisted LDS addresses (see the dQ kernel)
+#pragma unroll
+  for (int s = 0; s < NKS; ++s) row_addr[s] = I::off(l31, 2 * s + hh);
+#pragma unroll
+  for (int d = 0; d < NDT; ++d) {
+    const int e = 32 * d + 16 * cg + 4 * p4;
+    tr_lo[d] = I::off(4 * hh + q4, e >> 3) + (e & 7) * 2;
+    tr_hi[d] = I::off(4 * hh + q4 + 8, e >> 3) + (e & 7) * 2;
+  }
 
   f32x16_t dkt[NDT], dvt[NDT];
 #pragma unroll
@@ -352,7 +379,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
       for (int r = 0; r < 16; ++r) { sa[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
       for (int s = 0; s < NKS; ++s) {
-        const int a = I::off(32 * u + l31, 2 * s + hh);
+        const int a = row_addr[s] + 32 * u * I::PITCH;
         const bf16x8_t qfr = *(const bf16x8_t*)(cur + a);
         const bf16x8_t gfr = *(const bf16x8_t*)(cur + I::TILE + a);
         sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr, kf[s], sa, 0, 0, 0);
@@ -362,28 +389,33 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
       for (int c = 0; c < 4; ++c) {
         const f32x4_t l4 = *(const f32x4_t*)(lsev + 32 * u + 8 * c + 4 * hh);
         const f32x4_t d4 = *(const f32x4_t*)(delv + 32 * u + 8 * c + 4 * hh);
+        if (!diag) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float s2 = sa[4 * c + j] * p.scale_log2 + bias - l4[j];
-          if (diag) {
+          for (int j = 0; j < 4; ++j) {
+            const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sa[4 * c + j], p.scale_log2, bias) - l4[j]);
+            sa[4 * c + j] = pr;
+            dp[4 * c + j] = pr * (dp[4 * c + j] - d4[j]);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float s2 = sa[4 * c + j] * p.scale_log2 + bias - l4[j];
             const int q = qt * 64 + 32 * u + 8 * c + 4 * hh + j;
             if (kcol > q) s2 = -INF;
+            const float pr = __builtin_amdgcn_exp2f(s2);
+            sa[4 * c + j] = pr;
+            dp[4 * c + j] = pr * (dp[4 * c + j] - d4[j]);
           }
-          const float pr = __builtin_amdgcn_exp2f(s2);
-          sa[4 * c + j] = pr;
-          dp[4 * c + j] = pr * (dp[4 * c + j] - d4[j]);
         }
       }
 #pragma unroll
       for (int s2i = 0; s2i < 2; ++s2i) {
         const bf16x8_t pf = pack8(sa, 8 * s2i);
         const bf16x8_t dsf = pack8(dp, 8 * s2i);
-        const int qr = 32 * u + 16 * s2i + 4 * hh + q4;
+        const int roff = (32 * u + 16 * s2i) * I::PITCH;
 #pragma unroll
         for (int d = 0; d < NDT; ++d) {
-          const int e = 32 * d + 16 * cg + 4 * p4;
-          const int lo = I::off(qr, e >> 3) + (e & 7) * 2;
-          const int hi = I::off(qr + 8, e >> 3) + (e & 7) * 2;
+          const int lo = tr_lo[d] + roff, hi = tr_hi[d] + roff;
           const bf16x8_t gtf = tr_frag3(cur + I::TILE, lo, hi);  // dO^T
           const bf16x8_t qtf = tr_frag3(cur, lo, hi);            // Q^T
           dvt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gtf, pf, dvt[d], 0, 0, 0);

@@ -53,7 +53,7 @@ __device__ __forceinline__ bf16x8_t tr_frag2(const char* base, int addr_lo, int 
 }
 
 template <int D>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs p) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnFwdArgs p) {
   using Cfg = AttnCfg<D>;
   constexpr int KS = Cfg::KS, VS = Cfg::VS, CH = Cfg::CH, NCH = Cfg::NCH;
   constexpr int NKS = D / 16, NDT = D / 32;
@@ -159,49 +159,73 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs p) {
       }
     }
 
-    // ---- scale, masks ----
+    // ---- softmax update: interior tiles (no bias, no causal edge, full 64 keys) take a branch-free path with
+    // one fma + one exp per score; edge tiles take the general masked path ----
     const bool tail = (kt * 64 + 64 > p.Sk);
     const bool diag = p.causal && (kt * 64 + 63 > blockIdx.x * 128);  // some key may exceed some query
-    const bool use_bias = tail || (p.kbias != nullptr);
-    const float* biasv = (const float*)(cur + Cfg::KT + Cfg::VT);
-    float mx = NEG_INF;
+    const bool masked = tail || diag || (p.kbias != nullptr);
+    float alpha, psum = 0.f;
+    if (!masked) {
+      float mx = st[0][0];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        f32x4_t bz = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        if (use_bias) bz = *(const f32x4_t*)(biasv + 32 * t + 8 * c + 4 * hh);
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[t][r]);
+      mx *= p.scale_log2;  // scale > 0
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      const float neg_m = -m_new;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float s = st[t][4 * c + j] * p.scale_log2 + bz[j];
-          if (diag) {
-            const int key = kt * 64 + 32 * t + 8 * c + 4 * hh + j;
-            if (key > qrow) s = NEG_INF;
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(st[t][r], p.scale_log2, neg_m));
+          st[t][r] = e;
+          psum += e;
+        }
+    } else {
+      const float* biasv = (const float*)(cur + Cfg::KT + Cfg::VT);
+      float mx = NEG_INF;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const f32x4_t bz = *(const f32x4_t*)(biasv + 32 * t + 8 * c + 4 * hh);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float sc = st[t][4 * c + j] * p.scale_log2 + bz[j];
+            if (diag) {
+              const int key = kt * 64 + 32 * t + 8 * c + 4 * hh + j;
+              if (key > qrow) sc = NEG_INF;
+            }
+            st[t][4 * c + j] = sc;
+            mx = fmaxf(mx, sc);
           }
-          st[t][4 * c + j] = s;
-          mx = fmaxf(mx, s);
         }
       }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
+      alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+      m_run = m_new;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float e = __builtin_amdgcn_exp2f(st[t][r] - m_use);
+          st[t][r] = e;
+          psum += e;
+        }
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
-    m_run = m_new;
-    float psum = 0.f;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f(st[t][r] - m_use);
-        st[t][r] = e;
-        psum += e;
-      }
     l_run = l_run * alpha + psum;
+    if (__any(alpha != 1.f)) {  // lazy rescale: once the running max has settled nothing is multiplied
 #pragma unroll
-    for (int d = 0; d < NDT; ++d)
+      for (int d = 0; d < NDT; ++d)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) ot[d][r] *= alpha;
+        for (int r = 0; r < 16; ++r) ot[d][r] *= alpha;
+    }
 
     // ---- O^T += V^T · P^T ----
 #pragma unroll
