@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=2)
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--graph", action="store_true", help="replay the step as one hipGraph (single GPU, SGD); measured "
+                    "equal to eager launches at B=32 — the step is GPU-bound, not launch-bound")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI) | gloo (wiring tests on one GPU)")
     args = ap.parse_args()
 
@@ -159,21 +161,37 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    use_graph = args.graph and world == 1 and args.optimizer == "sgd"
     for _ in range(args.warmup):
         loss = ts.step(inputs, labels)
     sync()
     timer = GemmTimer()
-    t0 = time.perf_counter()
-    with timer:
-        for _ in range(args.steps):
+    if use_graph:
+        # events cannot be recorded inside a replayed graph: the roofline leg times one eager step instead
+        with timer:
             loss = ts.step(inputs, labels)
+            sync()
+        run = ts.capture(inputs, labels)
         sync()
-    dt = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = run(inputs, labels)
+        sync()
+        dt = time.perf_counter() - t0
+        timed_steps = 1
+    else:
+        t0 = time.perf_counter()
+        with timer:  # every gemm_nt launch of the timed steps is bracketed by HIP events on its launch stream
+            for _ in range(args.steps):
+                loss = ts.step(inputs, labels)
+            sync()
+        dt = time.perf_counter() - t0
+        timed_steps = args.steps
+    gsum = timer.summary()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    gsum = timer.summary()
     loss_val = float(loss.item())
 
     if rank == 0:
@@ -191,9 +209,9 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel (all bf16 NT GEMM launches of the timed steps)",
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
-                         "launches_per_step": gsum["launches"] / max(args.steps, 1),
+                         "launches_per_step": gsum["launches"] / timed_steps, "hip_graph": use_graph,
                          "avg_launch_us": gsum["seconds"] / max(gsum["launches"], 1) * 1e6,
-                         "gemm_nt_time_share": gsum["seconds"] / dt},
+                         "gemm_nt_time_share": gsum["seconds"] / timed_steps / (dt / args.steps)},
         }
         if not args.no_cpu_baseline:
             try:

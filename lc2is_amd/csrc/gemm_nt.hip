@@ -388,6 +388,141 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_dma_kernel(Gemm
     gemm_epilogue<TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lane);
 }
 
+// ---- ping-pong variant: the two waves of every SIMD alternate LDS-read and MFMA segments ------------------
+// 256x256x64 tile, 8 waves (2x4, 128x64 each).  Waves 0-3 and 4-7 pair up on the four SIMDs; the second group runs
+// one barrier behind the first, so between any two barriers one wave of each SIMD issues its 12 ds_read_b128 (and,
+// once per K tile, its 8 LDS-DMA pieces) while its partner issues 32 MFMAs from registers: the matrix pipe never
+// waits for LDS.  The DMA is issued from inline asm (global_load_lds_dwordx4) so that hipcc, which would
+// otherwise drain vmcnt(0) before the next ds_read, leaves it in flight across three barriers; its completion
+// is waited by hand (vmcnt(0)) before the barrier that precedes the first read of the tile.
+//   interval 4t+1 : both groups issue the DMA of K tile t+1 into the other buffer (all reads of that buffer
+//                   retired two barriers earlier)
+//   interval 4t+3 : both groups wait vmcnt(0) before the closing barrier; tile t+1 is first read in interval 4t+4
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+
+__global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmNtArgs p) {
+  constexpr int BM = 256, BN = 256, WAVES_N = 4, BK = 64;
+  constexpr int WM = 128, WN = 64, TM = 8, TN = 4;
+  constexpr int PIECES = 4;  // 1-KiB pieces (8 rows x 128 B) per wave per operand tile
+  constexpr int STAGE = (BM + BN) * 128;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)LDS_PTR(smem);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+  const int grp = wm;  // waves 0-3: group 0, waves 4-7: group 1 (SIMD partners)
+  const int ntn = (p.N + BN - 1) / BN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+
+  // per-lane DMA sources (rows clamped into the matrix: rows past M / N only feed outputs that are never stored)
+  const int lrow = lane >> 3, lch = (lane & 7) ^ (lane >> 3);
+  const char* a_src[PIECES];
+  const char* w_src[PIECES];
+#pragma unroll
+  for (int j = 0; j < PIECES; ++j) {
+    int ar = m0 + 8 * (wid * PIECES + j) + lrow;
+    int wr = n0 + 8 * (wid * PIECES + j) + lrow;
+    ar = ar < p.M ? ar : p.M - 1;
+    wr = wr < p.N ? wr : p.N - 1;
+    a_src[j] = (const char*)p.A + ((size_t)ar * p.lda + lch * 8) * 2;
+    w_src[j] = (const char*)p.W + ((size_t)wr * p.ldw + lch * 8) * 2;
+  }
+  const unsigned a_dst = lds_base + wid * PIECES * 1024;
+  const unsigned w_dst = lds_base + BM * 128 + wid * PIECES * 1024;
+
+#define PP_ISSUE(BUF, KB)                                                        \
+  do {                                                                           \
+    _Pragma("unroll") for (int j = 0; j < PIECES; ++j)                           \
+        glds16(a_src[j] + (KB), a_dst + (BUF)*STAGE + j * 1024);                 \
+    _Pragma("unroll") for (int j = 0; j < PIECES; ++j)                           \
+        glds16(w_src[j] + (KB), w_dst + (BUF)*STAGE + j * 1024);                 \
+  } while (0)
+#define PP_BARRIER()                          \
+  do {                                        \
+    __builtin_amdgcn_sched_barrier(0);        \
+    __builtin_amdgcn_s_barrier();             \
+    __builtin_amdgcn_sched_barrier(0);        \
+  } while (0)
+#define PP_WAIT_DMA() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+  f32x4_t acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, g = lane >> 4, sw = lane & 7;
+  const int x_frag = (wm * WM + frow) * 128;
+  const int w_frag = BM * 128 + (wn * WN + frow) * 128;
+  const int kc_off0 = ((0 + g) ^ sw) << 4, kc_off1 = ((4 + g) ^ sw) << 4;
+  const int nk = p.K / BK;
+
+  PP_ISSUE(0, 0);
+  PP_WAIT_DMA();
+  PP_BARRIER();
+  if (grp == 1) PP_BARRIER();  // stagger: group 1 runs one segment behind group 0
+
+  bf16x8_t xf[TM], wf[TN];
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* cur = smem + (kt & 1) * STAGE;
+    const int nbuf = (kt + 1) & 1;
+    const bool more = (kt + 1) < nk;
+    const int kb = (kt + 1) * BK * 2;
+    // ---- phase k-substep 0: LOAD segment ----
+    if (grp == 1 && more) PP_ISSUE(nbuf, kb);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) xf[j] = *(const bf16x8_t*)(cur + x_frag + j * 16 * 128 + kc_off0);
+#pragma unroll
+    for (int i = 0; i < TN; ++i) wf[i] = *(const bf16x8_t*)(cur + w_frag + i * 16 * 128 + kc_off0);
+    PP_BARRIER();
+    // ---- COMPUTE segment ----
+    if (grp == 0 && more) PP_ISSUE(nbuf, kb);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    PP_BARRIER();
+    // ---- phase k-substep 1: LOAD segment ----
+#pragma unroll
+    for (int j = 0; j < TM; ++j) xf[j] = *(const bf16x8_t*)(cur + x_frag + j * 16 * 128 + kc_off1);
+#pragma unroll
+    for (int i = 0; i < TN; ++i) wf[i] = *(const bf16x8_t*)(cur + w_frag + i * 16 * 128 + kc_off1);
+    if (grp == 1) PP_WAIT_DMA();
+    PP_BARRIER();
+    // ---- COMPUTE segment ----
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    if (grp == 0) PP_WAIT_DMA();
+    PP_BARRIER();
+  }
+  if (grp == 0) PP_BARRIER();  // even out the barrier count
+  __syncthreads();
+#undef PP_ISSUE
+#undef PP_BARRIER
+#undef PP_WAIT_DMA
+  if (p.staged_epi)
+    gemm_epilogue_lds<TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lane, wid, smem);
+  else
+    gemm_epilogue<TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lane);
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 int launch_cfg(const GemmNtArgs& a, hipStream_t stream) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
@@ -417,6 +552,20 @@ int launch_dma(const GemmNtArgs& a, hipStream_t stream) {
   }
   const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
   hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(NT), LDS, stream, a);
+  return lc2is_check_launch();
+}
+
+int launch_pp(const GemmNtArgs& a, hipStream_t stream) {
+  constexpr int LDS = 2 * (256 + 256) * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm_nt_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
+        hipSuccess)
+      return LC2IS_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int ntm = (a.M + 255) / 256, ntn = (a.N + 255) / 256;
+  hipLaunchKernelGGL(gemm_nt_pp_kernel, dim3(ntm * ntn), dim3(512), LDS, stream, a);
   return lc2is_check_launch();
 }
 
@@ -459,6 +608,7 @@ extern "C" int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw
     case 4: return launch_dma<256, 256, 2, 4>(a, stream);
     case 5: return launch_dma<256, 128, 4, 2>(a, stream);
     case 6: return launch_dma<128, 128, 2, 2>(a, stream);
+    case 7: return launch_pp(a, stream);
     default: return LC2IS_ERR_UNSUPPORTED;
   }
 }

@@ -17,6 +17,7 @@ def _rel(a, b):
     (300, 192, 128, 1), (300, 192, 128, 2), (300, 192, 128, 3), (1025, 768, 768, 0), (4100, 2304, 768, 0),
     (129, 152, 512, 0), (77, 64, 64, 3), (2050, 768, 3072, 2), (2050, 768, 3072, 4), (300, 192, 128, 4),
     (1025, 2304, 768, 5), (300, 192, 128, 5), (515, 384, 192, 6), (4100, 768, 768, 4),
+    (2050, 768, 3072, 7), (300, 192, 128, 7), (4100, 768, 768, 7), (1025, 2304, 64, 7),
 ])
 def test_gemm_nt_plain(dev, M, N, K, cfg):
     from lc2is_amd import ops
@@ -41,7 +42,7 @@ def test_gemm_nt_asymmetric_identity(dev):
     assert torch.equal(of, w.float().T.contiguous())
 
 
-@pytest.mark.parametrize("cfg", [0, 4, 5, 6])
+@pytest.mark.parametrize("cfg", [0, 4, 5, 6, 7])
 @pytest.mark.parametrize("act", ["quick_gelu", "relu"])
 def test_gemm_nt_activation_and_backward_epilogue(dev, act, cfg):
     from lc2is_amd import ops
@@ -145,3 +146,18 @@ def test_layernorm_fwd_bwd(dev, M, C):
     xd.grad = None
     torch.nn.functional.layer_norm(xd, (C,), gd, bd, 1e-5).backward(dyb.double())
     assert _rel(dxf2, xd.grad) < 1e-5
+
+
+def test_gemm_nt_pingpong_is_bitwise_equal_to_simple_pipeline(dev):
+    """The ping-pong kernel (hand-placed waits, staggered wave groups) accumulates in the same order as the
+    simple LDS-DMA kernel: any race in its schedule shows up as a bit difference.  Several shapes x repeats."""
+    from lc2is_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(77)
+    for (M, N, K) in [(32800, 768, 768), (8200, 3072, 768), (4100, 768, 3072), (1025, 2304, 768), (257, 256, 128)]:
+        a = _bf(torch.randn(M, K, generator=g)).to(dev)
+        w = _bf(torch.randn(N, K, generator=g) * 0.05).to(dev)
+        bias = torch.randn(N, generator=g).to(dev)
+        ref, reff, _ = ops.gemm_nt(a, w, bias, out_bf16=True, out_f32=True, tile_cfg=4)
+        for _ in range(5):
+            ob, of, _ = ops.gemm_nt(a, w, bias, out_bf16=True, out_f32=True, tile_cfg=7)
+            assert torch.equal(of, reff) and torch.equal(ob, ref), (M, N, K)
