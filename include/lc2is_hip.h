@@ -182,6 +182,28 @@ int lc2is_ce_nchw_bwd(const float* logits, const int64_t* labels, const float* l
                       float grad_scale, float* dlogits, int B, int C, long HW, long ignore_index,
                       lc2is_stream_t stream);
 
+/* ---- multi-scale decoder glue (BASELINE config 5; all channels-last token tensors [B, h*w, C]) --------
+ * bilinear xS upsample (align_corners=False) forward / backward.
+ * replaces: rearrange + F.interpolate(mode="bilinear", scale_factor=S) + rearrange at
+ *   model/hierarchical.py:103-109,146-149,166-170, model/decoder.py:66-72,106-109, model/ftn.py:113,155. */
+int lc2is_bilinear_up_fwd(const float* in, float* out_f32, void* out_bf16, int B, int h, int w, int C, int S,
+                          lc2is_stream_t stream);
+int lc2is_bilinear_up_bwd(const float* dout, float* din_f32, void* din_bf16, int B, int h, int w, int C, int S,
+                          int accumulate, lc2is_stream_t stream);
+/* Spatial-reduction conv operand: out[(b,y,x)][(2i+j)*C + c] = in[(b,2y+i,2x+j)][c] (bf16); scatter != 0 applies
+ * the inverse map (its backward).  replaces: the im2col of Conv2d(d, d, kernel_size=2, stride=2) in
+ *   SRTransformer*._sa_block (model/hierarchical.py:191,214; model/decoder.py:124). */
+int lc2is_sr_gather(const void* src_bf16, void* dst_bf16, int B, int h, int w, int C, int scatter,
+                    lc2is_stream_t stream);
+/* y = x / max(||x||_2, eps) over the last dim (F.normalize, model/final.py:353-354) and its backward. */
+int lc2is_l2norm_fwd(const float* x, float* y_f32, void* y_bf16, float* inv_norm, int M, int C, float eps,
+                     lc2is_stream_t stream);
+int lc2is_l2norm_bwd(const float* dy, const float* x, const float* inv_norm, float* dx, int M, int C, float eps,
+                     lc2is_stream_t stream);
+/* out = a + b (+ c) (+ d)  — torch.stack(...).sum(0) of model/hierarchical.py:128-129. */
+int lc2is_add_n(const float* a, const float* b, const float* c, const float* d, float* out_f32, void* out_bf16,
+                size_t n, lc2is_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

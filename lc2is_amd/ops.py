@@ -44,6 +44,12 @@ _ARGTYPES = {
     "lc2is_ce_nchw_fwd": [_P, _P, _P, _P, _I, _I, C.c_long, C.c_long, _P],
     "lc2is_ce_nchw_bwd": [_P, _P, _P, _P, _F, _P, _I, _I, C.c_long, C.c_long, _P],
     "lc2is_upsample_bwd_nchw": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "lc2is_bilinear_up_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "lc2is_bilinear_up_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "lc2is_sr_gather": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "lc2is_l2norm_fwd": [_P, _P, _P, _P, _I, _I, _F, _P],
+    "lc2is_l2norm_bwd": [_P, _P, _P, _P, _I, _I, _F, _P],
+    "lc2is_add_n": [_P, _P, _P, _P, _P, _P, _Z, _P],
 }
 _bound = {}
 
@@ -459,3 +465,79 @@ def upsample_bwd_nchw(dhi, B: int, h: int, w: int, C: int, S: int, mode: int, ld
     _lib.check(_fn("lc2is_upsample_bwd_nchw")(_ptr(dhi), _ptr(dlo), ld, B, h, w, C, S, mode, _stream()),
                "upsample_bwd_nchw")
     return dlo
+
+
+def _dense(t, dtype, name):
+    _chk(t, dtype, name)
+    if t is not None and not t.is_contiguous():
+        raise RuntimeError(f"lc2is_amd: {name} must be contiguous")
+
+
+def bilinear_up_fwd(x, B: int, h: int, w: int, S: int, *, want_f32: bool = True, want_bf16: bool = False):
+    """x fp32 [B*h*w, C] channels-last tokens -> ([B*h*S*w*S, C] fp32 or None, bf16 twin or None)."""
+    _dense(x, torch.float32, "x")
+    Cc = x.shape[1]
+    n = B * h * S * w * S
+    of = torch.empty((n, Cc), dtype=torch.float32, device=x.device) if want_f32 else None
+    ob = torch.empty((n, Cc), dtype=torch.bfloat16, device=x.device) if want_bf16 else None
+    _lib.check(_fn("lc2is_bilinear_up_fwd")(_ptr(x), _ptr(of), _ptr(ob), B, h, w, Cc, S, _stream()), "bilinear_up_fwd")
+    return of, ob
+
+
+def bilinear_up_bwd(dout, B: int, h: int, w: int, S: int, *, din=None, accumulate: bool = False, want_bf16: bool = False):
+    _dense(dout, torch.float32, "dout")
+    Cc = dout.shape[1]
+    if din is None:
+        din = torch.empty((B * h * w, Cc), dtype=torch.float32, device=dout.device)
+        accumulate = False
+    _dense(din, torch.float32, "din")
+    d16 = torch.empty((B * h * w, Cc), dtype=torch.bfloat16, device=dout.device) if want_bf16 else None
+    _lib.check(_fn("lc2is_bilinear_up_bwd")(_ptr(dout), _ptr(din), _ptr(d16), B, h, w, Cc, S, int(accumulate), _stream()),
+               "bilinear_up_bwd")
+    return din, d16
+
+
+def sr_gather(x16, B: int, h: int, w: int, scatter: bool = False):
+    """gather: bf16 [B*h*w, C] -> [B*h*w/4, 4C];  scatter: bf16 [B*h*w/4, 4C] -> [B*h*w, C]."""
+    _dense(x16, torch.bfloat16, "x")
+    if scatter:
+        Cc = x16.shape[1] // 4
+        out = torch.empty((B * h * w, Cc), dtype=torch.bfloat16, device=x16.device)
+    else:
+        Cc = x16.shape[1]
+        out = torch.empty((B * h * w // 4, 4 * Cc), dtype=torch.bfloat16, device=x16.device)
+    _lib.check(_fn("lc2is_sr_gather")(_ptr(x16), _ptr(out), B, h, w, Cc, int(scatter), _stream()), "sr_gather")
+    return out
+
+
+def l2norm_fwd(x, eps: float = 1e-12, *, want_f32: bool = True, want_bf16: bool = True):
+    _dense(x, torch.float32, "x")
+    M, Cc = x.shape
+    yf = torch.empty_like(x) if want_f32 else None
+    yb = torch.empty((M, Cc), dtype=torch.bfloat16, device=x.device) if want_bf16 else None
+    inv = torch.empty((M,), dtype=torch.float32, device=x.device)
+    _lib.check(_fn("lc2is_l2norm_fwd")(_ptr(x), _ptr(yf), _ptr(yb), _ptr(inv), M, Cc, eps, _stream()), "l2norm_fwd")
+    return yf, yb, inv
+
+
+def l2norm_bwd(dy, x, inv, eps: float = 1e-12):
+    _dense(dy, torch.float32, "dy"); _dense(x, torch.float32, "x")
+    M, Cc = x.shape
+    dx = torch.empty_like(x)
+    _lib.check(_fn("lc2is_l2norm_bwd")(_ptr(dy), _ptr(x), _ptr(inv), _ptr(dx), M, Cc, eps, _stream()), "l2norm_bwd")
+    return dx
+
+
+def add_n(tensors, *, want_f32: bool = True, want_bf16: bool = False):
+    """Elementwise sum of 2..4 fp32 tensors of equal shape."""
+    if not 2 <= len(tensors) <= 4:
+        raise RuntimeError("lc2is_amd.add_n takes 2 to 4 tensors")
+    for t in tensors:
+        _chk(t, torch.float32, "addend", None)
+        if not t.is_contiguous() or t.shape != tensors[0].shape:
+            raise RuntimeError("lc2is_amd.add_n: addends must be contiguous and equally shaped")
+    ps = [_ptr(t) for t in tensors] + [None] * (4 - len(tensors))
+    of = torch.empty_like(tensors[0]) if want_f32 else None
+    ob = torch.empty(tensors[0].shape, dtype=torch.bfloat16, device=tensors[0].device) if want_bf16 else None
+    _lib.check(_fn("lc2is_add_n")(*ps, _ptr(of), _ptr(ob), tensors[0].numel(), _stream()), "add_n")
+    return of, ob

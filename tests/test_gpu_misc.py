@@ -174,3 +174,52 @@ def test_ce_nchw(dev):
     assert abs(loss[0].item() / loss[1].item() - ref.item()) < 1e-5
     d = ops.ce_nchw_bwd(logits, labels, lse, None, 1.0 / (B * H * H))
     assert _rel(d, ld.grad) < 1e-5
+
+
+@pytest.mark.parametrize("B,h,C,S", [(2, 8, 128, 2), (1, 16, 64, 4), (2, 5, 192, 2), (1, 32, 512, 2)])
+def test_bilinear_channels_last(dev, B, h, C, S):
+    from lc2is_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(B + h + C)
+    x = torch.randn(B * h * h, C, generator=g).to(dev)
+    of, ob = ops.bilinear_up_fwd(x, B, h, h, S, want_bf16=True)
+    xn = x.double().reshape(B, h, h, C).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    ref = F.interpolate(xn, scale_factor=S, mode="bilinear")
+    refl = ref.permute(0, 2, 3, 1).reshape(B * h * S * h * S, C)
+    assert (of.double() - refl).abs().max().item() < 1e-5 and _rel(ob.float(), refl) < 4e-3
+    dout = torch.randn(B * h * S * h * S, C, generator=g).to(dev)
+    ref.backward(dout.double().reshape(B, h * S, h * S, C).permute(0, 3, 1, 2))
+    din, d16 = ops.bilinear_up_bwd(dout, B, h, h, S, want_bf16=True)
+    rg = xn.grad.permute(0, 2, 3, 1).reshape(B * h * h, C)
+    assert _rel(din, rg) < 1e-5 and _rel(d16.float(), rg) < 4e-3
+    din2, _ = ops.bilinear_up_bwd(dout, B, h, h, S, din=din.clone(), accumulate=True)
+    assert _rel(din2, 2 * rg) < 1e-5
+
+
+def test_sr_gather_l2norm_addn(dev):
+    from lc2is_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(5)
+    B, h, C = 2, 8, 64
+    x = torch.randn(B * h * h, C, generator=g).bfloat16().to(dev)
+    gth = ops.sr_gather(x, B, h, h)
+    w = torch.randn(C, C, 2, 2, generator=g).bfloat16().to(dev)
+    conv = F.conv2d(x.double().reshape(B, h, h, C).permute(0, 3, 1, 2), w.double(), stride=2)
+    wp = w.double().reshape(C, C, 4).transpose(1, 2).reshape(C, 4 * C)          # [co][(i*2+j)*C + ci]
+    mine = (gth.double() @ wp.T).reshape(B, h // 2, h // 2, C).permute(0, 3, 1, 2)
+    assert (mine - conv).abs().max().item() < 1e-9
+    assert torch.equal(ops.sr_gather(gth, B, h, h, scatter=True), x)
+    xf = torch.randn(300, 512, generator=g).to(dev)
+    xf[7] = 0
+    yf, yb, inv = ops.l2norm_fwd(xf)
+    xd = xf.double().requires_grad_(True)
+    ref = F.normalize(xd, dim=1, p=2)
+    assert (yf.double() - ref).abs().max().item() < 1e-6 and _rel(yb.float(), ref) < 4e-3
+    dy = torch.randn(300, 512, generator=g).to(dev)
+    ref.backward(dy.double())
+    dx = ops.l2norm_bwd(dy, xf, inv)
+    keep = torch.ones(300, dtype=torch.bool); keep[7] = False
+    assert _rel(dx[keep.to(dev)], xd.grad[keep.to(dev)]) < 1e-5
+    a, b, c, d = (torch.randn(1000, 64, generator=g).to(dev) for _ in range(4))
+    s4, s4b = ops.add_n([a, b, c, d], want_bf16=True)
+    assert torch.allclose(s4, a + b + c + d, atol=1e-6) and torch.equal(s4b, (a + b + c + d).bfloat16())
+    s2, _ = ops.add_n([a, b])
+    assert torch.equal(s2, a + b)
