@@ -373,3 +373,99 @@ def compute_miou(outputs: Tensor, labels: Tensor, n_class: int = 151, ignore_ind
             ious.append(inter / union if union else 0.0)
         vals.append(sum(ious) / len(ious) if ious else float("nan"))
     return float(sum(vals) / len(vals))
+
+
+# ----------------------------------------------------------------------------------------------------------
+# multi-scale decoders (BASELINE config 5): model/hierarchical.py, model/decoder.py:36-134
+# ----------------------------------------------------------------------------------------------------------
+def _mha_packed(sd: dict, pre: str, q_in: Tensor, kv_in: Tensor, nhead: int, bias: Tensor | None = None) -> Tensor:
+    """nn.MultiheadAttention with a packed in_proj_weight [3C,C] (q from q_in, k/v from kv_in), optional biases
+    (absent under the torch-2.10 `bias` drift)."""
+    C = q_in.shape[-1]
+    w = sd[pre + "in_proj_weight"]
+    b = sd.get(pre + "in_proj_bias")
+    bq, bk, bv = (b.split(C) if b is not None else (None, None, None))
+    q = linear(q_in, w[:C], bq)
+    k = linear(kv_in, w[C:2 * C], bk)
+    v = linear(kv_in, w[2 * C:], bv)
+    a = mha_core(q, k, v, nhead, (C // nhead) ** -0.5, bias)
+    return linear(a, sd[pre + "out_proj.weight"], sd.get(pre + "out_proj.bias"))
+
+
+def sr_reduce(sd: dict, pre: str, x: Tensor) -> Tensor:
+    """Conv2d(d, d, kernel=2, stride=2) over the token grid + LayerNorm (model/hierarchical.py:189-193,212-216)."""
+    B, P, C = x.shape
+    H = int(P ** 0.5)
+    w = sd[pre + "sr.weight"]                                     # [C, C, 2, 2]
+    xg = x.reshape(B, H // 2, 2, H // 2, 2, C).permute(0, 1, 3, 5, 2, 4).reshape(B, (H // 2) ** 2, C * 4)
+    r = xg @ w.reshape(C, C * 4).transpose(0, 1) + sd[pre + "sr.bias"]
+    return layer_norm(r, sd[pre + "norm.weight"], sd[pre + "norm.bias"], 1e-5)
+
+
+def sr_cross_layer(sd: dict, pre: str, tgt: Tensor, memory: Tensor, nhead: int, eps: float = 1e-5) -> Tensor:
+    """SRTransformerCrossA / SRTransformerDecoder forward (post-norm TransformerDecoderLayer whose self-attention
+    keys/values are the spatially reduced tokens): model/hierarchical.py:201-225, model/decoder.py:113-134,
+    torch:nn/modules/transformer.py:1147-1156."""
+    g = lambda k: sd.get(pre + k)  # noqa: E731
+    x = tgt
+    x = layer_norm(x + _mha_packed(sd, pre + "self_attn.", x, sr_reduce(sd, pre, x), nhead), g("norm1.weight"),
+                   g("norm1.bias"), eps)
+    x = layer_norm(x + _mha_packed(sd, pre + "multihead_attn.", x, memory, nhead), g("norm2.weight"), g("norm2.bias"), eps)
+    ff = linear(torch.relu(linear(x, g("linear1.weight"), g("linear1.bias"))), g("linear2.weight"), g("linear2.bias"))
+    return layer_norm(x + ff, g("norm3.weight"), g("norm3.bias"), eps)
+
+
+def sr_self_layer(sd: dict, pre: str, src: Tensor, nhead: int, eps: float = 1e-5) -> Tensor:
+    """SRTransformerSelfA forward (post-norm TransformerEncoderLayer), model/hierarchical.py:174-199."""
+    g = lambda k: sd.get(pre + k)  # noqa: E731
+    x = src
+    x = layer_norm(x + _mha_packed(sd, pre + "self_attn.", x, sr_reduce(sd, pre, x), nhead), g("norm1.weight"),
+                   g("norm1.bias"), eps)
+    ff = linear(torch.relu(linear(x, g("linear1.weight"), g("linear1.bias"))), g("linear2.weight"), g("linear2.bias"))
+    return layer_norm(x + ff, g("norm2.weight"), g("norm2.bias"), eps)
+
+
+def _up2_tokens(x: Tensor, factor: int = 2) -> Tensor:
+    B, P, C = x.shape
+    H = int(P ** 0.5)
+    y = upsample2d(x.reshape(B, H, H, C).permute(0, 3, 1, 2), scale_factor=factor, mode="bilinear")
+    return y.permute(0, 2, 3, 1).reshape(B, P * factor * factor, C)
+
+
+def attn_block(sd: dict, pre: str, x: Tensor, memory: Tensor | None, nhead: int, depth: int, layer_key: str) -> Tensor:
+    """CrossABlock / SelfABlock / FTNBlock: `depth` applications of ONE shared layer, then bilinear x2
+    (model/hierarchical.py:140-172, model/decoder.py:103-111)."""
+    for _ in range(depth):
+        x = sr_cross_layer(sd, pre + layer_key, x, memory, nhead) if memory is not None else \
+            sr_self_layer(sd, pre + layer_key, x, nhead)
+    return _up2_tokens(x)
+
+
+def hierarchical(sd: dict, pre: str, visual: list, textual: Tensor | None, nhead: int, depth=(1, 1, 1),
+                 layer_key: str = "layers.0.") -> Tensor:
+    """HierarchicalCrossA / HierarchicalSelfA / FTNDecoder forward (model/hierarchical.py:37-69,99-131,
+    model/decoder.py:62-94): top-down pyramid, reads only visual[0] and visual[3]."""
+    L = lambda name, x: linear(x, sd[pre + name + ".weight"], sd[pre + name + ".bias"])  # noqa: E731
+    t4 = visual[3]
+    t3 = L("linear_stage_3", _up2_tokens(t4))
+    t2 = L("linear_stage_2", _up2_tokens(t3))
+    t1 = L("linear2_stage_1", visual[0])
+    t4, t3, t2 = L("linear2_stage_4", t4), L("linear2_stage_3", t3), L("linear2_stage_2", t2)
+    for i in range(3):
+        t4 = attn_block(sd, f"{pre}attention_stage_4.{i}.", t4, textual, nhead, depth[2], layer_key)
+    for i in range(2):
+        t3 = attn_block(sd, f"{pre}attention_stage_3.{i}.", t3, textual, nhead, depth[1], layer_key)
+    t2 = attn_block(sd, f"{pre}attention_stage_2.0.", t2, textual, nhead, depth[0], layer_key)
+    return t1 + t2 + t3 + t4
+
+
+def score_map_tail(visual_embeddings: Tensor, text_embeddings: Tensor, scale: int = 4) -> Tensor:
+    """model/final.py:350-356 (same ops at model/model.py:204-212, model/ftn.py:56-62): tokens -> NCHW, L2-normalise
+    both sides over channels, einsum('bchw,bkc->bkhw'), bilinear x4."""
+    B, P, C = visual_embeddings.shape
+    H = int(P ** 0.5)
+    v = visual_embeddings.reshape(B, H, H, C)
+    v = v / v.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    t = text_embeddings / text_embeddings.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    score = torch.einsum("bhwc,bkc->bkhw", v, t)
+    return upsample2d(score, scale_factor=scale, mode="bilinear")

@@ -1,0 +1,20 @@
+"""Deterministic weights shared by tools/make_golden.py (which loads them into the REFERENCE modules) and the
+tests (which load them into the oracle / the HIP modules): fixtures then only need inputs and outputs."""
+import torch
+
+
+def make_weights(shapes: dict, seed: int) -> dict:
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for name in sorted(shapes):
+        shape = tuple(shapes[name])
+        if "norm" in name and name.endswith("weight"):
+            out[name] = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        elif name.endswith("bias"):
+            out[name] = 0.05 * torch.randn(shape, generator=g)
+        else:
+            fan_in = 1
+            for s in shape[1:]:
+                fan_in *= s
+            out[name] = torch.randn(shape, generator=g) * (max(fan_in, 1) ** -0.5)
+    return out

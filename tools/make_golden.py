@@ -196,12 +196,89 @@ def make_ops(R):
     print("ops:", sorted(fx.keys()))
 
 
+def _patch_sr_is_causal(cls):
+    """torch 2.10 calls `_sa_block(x, mask, kpm, is_causal)`; the reference's overrides take 3 arguments
+    (SURVEY.md §2 drift #2).  Harness-side adapter: accept and drop `is_causal`; the method body stays the reference's."""
+    orig = cls._sa_block
+    if getattr(orig, "_adapted", False):
+        return
+
+    def adapted(self, x, attn_mask, key_padding_mask, is_causal=False):
+        return orig(self, x, attn_mask, key_padding_mask)
+
+    adapted._adapted = True
+    cls._sa_block = adapted
+
+
+def make_hier(R):
+    """HierarchicalCrossA / HierarchicalSelfA (model/hierarchical.py) and FTNDecoder (model/decoder.py:36-94) at
+    reduced dims, weights from tests/golden_util.make_weights (not stored), forward + backward."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    from golden_util import make_weights
+    import model.hierarchical as rh
+    for cls in (rh.SRTransformerCrossA, rh.SRTransformerSelfA, R["rdec"].SRTransformerDecoder):
+        _patch_sr_is_causal(cls)
+    in_dims, dim, nhead = [64, 128, 192, 256], 128, 2
+    g = torch.Generator().manual_seed(31)
+    B, K = 2, 10
+    visual = [torch.randn(B, p, c, generator=g) for p, c in zip((256, 64, 16, 4), in_dims)]
+    textual = torch.randn(B, K, dim, generator=g)
+    fx = dict(visual0=visual[0], visual1=visual[1], visual2=visual[2], visual3=visual[3], textual=textual)
+    specs = dict(
+        cross=(lambda: rh.HierarchicalCrossA(in_dims, [2, 1, 1], dim, nhead=nhead, dropout=0, batch_first=True), True, 41),
+        selfa=(lambda: rh.HierarchicalSelfA(in_dims, [1, 1, 2], dim, nhead=nhead, dropout=0, batch_first=True), False, 42),
+        ftn=(lambda: R["rdec"].FTNDecoder(in_dims, dim, dropout=0), True, 43),
+    )
+    for name, (ctor, uses_text, seed) in specs.items():
+        m = ctor().train()
+        params = dict(m.named_parameters())  # shared layers appear once
+        shapes = {k: list(v.shape) for k, v in params.items()}
+        w = make_weights(shapes, seed)
+        with torch.no_grad():
+            for k, p in params.items():
+                p.copy_(w[k])
+        vis = [v.clone().requires_grad_(True) for v in visual]
+        txt = textual.clone().requires_grad_(True)
+        out = m(vis, txt) if uses_text else m(vis)
+        dout = torch.randn(out.shape, generator=g)
+        out.backward(dout)
+        fx[name] = dict(shapes={k: torch.tensor(v) for k, v in shapes.items()}, seed=torch.tensor(seed), out=out.detach(),
+                        dout=dout, dvisual0=vis[0].grad.clone(), dvisual3=vis[3].grad.clone(),
+                        dvisual1_absmax=vis[1].grad.abs().max() if vis[1].grad is not None else torch.tensor(0.0),
+                        dtextual=txt.grad.clone() if uses_text else torch.zeros(1),
+                        grad_stats={k: torch.stack([p.grad.sum(), p.grad.abs().sum()]) for k, p in params.items()},
+                        grad_full={k: params[k].grad.clone() for k in list(params)[:0] +
+                                   [kk for kk in params if kk.endswith("sr.weight") or kk.endswith("linear_stage_3.weight")
+                                    or kk.endswith("norm.weight")][:6]})
+    # score-map tail (model/final.py:350-356; final.py itself cannot be imported — un-vendored DenseCLIP — so the
+    # same torch calls are issued here)
+    import torch.nn.functional as F
+    from einops import rearrange
+    ve = torch.randn(2, 64, 128, generator=g, requires_grad=True)
+    te = torch.randn(2, 10, 128, generator=g, requires_grad=True)
+    v = rearrange(ve, "b (h w) c -> b c h w", h=8)
+    v = F.normalize(v, dim=1, p=2)
+    t = F.normalize(te, dim=2, p=2)
+    sm = F.interpolate(torch.einsum("bchw,bkc->bkhw", v, t), mode="bilinear", scale_factor=4)
+    lab = torch.randint(0, 10, (2, 32, 32), generator=g)
+    loss = nn.CrossEntropyLoss()(sm, lab)
+    loss.backward()
+    fx["tail"] = dict(ve=ve.detach(), te=te.detach(), score=sm.detach(), labels=lab, loss=loss.detach(), dve=ve.grad.clone(),
+                      dte=te.grad.clone())
+    torch.save(fx, OUT / "hier_tiny.pt")
+    print("hier:", {k: (tuple(v["out"].shape) if isinstance(v, dict) and "out" in v else None) for k, v in fx.items()})
+
+
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
     R = _ref_imports()
+    if len(sys.argv) > 1 and sys.argv[1] == "hier":
+        make_hier(R)
+        return
     make_base_tiny(R)
     make_decoder_d96(R)
     make_ops(R)
+    make_hier(R)
     # the reference's only data fixture on this path — copied as-is
     protos = torch.load(REF / "model" / "ade20k_prototypes.pt", weights_only=True)
     torch.save(protos.clone(), OUT / "ade20k_prototypes.pt")
