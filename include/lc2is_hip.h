@@ -195,6 +195,8 @@ int lc2is_bilinear_up_bwd(const float* dout, float* din_f32, void* din_bf16, int
  *   SRTransformer*._sa_block (model/hierarchical.py:191,214; model/decoder.py:124). */
 int lc2is_sr_gather(const void* src_bf16, void* dst_bf16, int B, int h, int w, int C, int scatter,
                     lc2is_stream_t stream);
+/* Backward of the gather accumulated onto an fp32 gradient stream: dst[(b,2y+i,2x+j)][c] += src[(b,y,x)][(2i+j)*C+c]. */
+int lc2is_sr_scatter_add_f32(const void* src_bf16, float* dst_f32, int B, int h, int w, int C, lc2is_stream_t stream);
 /* y = x / max(||x||_2, eps) over the last dim (F.normalize, model/final.py:353-354) and its backward. */
 int lc2is_l2norm_fwd(const float* x, float* y_f32, void* y_bf16, float* inv_norm, int M, int C, float eps,
                      lc2is_stream_t stream);

@@ -115,6 +115,28 @@ __global__ __launch_bounds__(256) void sr_gather_kernel(const bf16_t* __restrict
   }
 }
 
+// dst32[(b, 2y+i, 2x+j)][c] += src16[(b, y, x)][q*C + c]   (backward of the gather, accumulated onto the fp32 stream)
+__global__ __launch_bounds__(256) void sr_scatter_add_kernel(const bf16_t* __restrict__ src, float* dst, int B, int h, int w,
+                                                              int C) {
+  const int C4 = C >> 2, h2 = h >> 1, w2 = w >> 1;
+  const size_t total = (size_t)B * h2 * w2 * 4 * C4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c4 = (int)(i % C4);
+    size_t r = i / C4;
+    const int q = (int)(r & 3);
+    r >>= 2;
+    const int x = (int)(r % w2), y = (int)((r / w2) % h2), b = (int)(r / ((size_t)w2 * h2));
+    const size_t fine = ((size_t)b * h + 2 * y + (q >> 1)) * w + 2 * x + (q & 1);
+    const size_t coarse = ((size_t)b * h2 + y) * w2 + x;
+    const uint2 pk = *(reinterpret_cast<const uint2*>(src + (coarse * 4 + q) * C) + c4);
+    float4* d = reinterpret_cast<float4*>(dst + fine * C) + c4;
+    float4 v = *d;
+    v.x += bf16_to_f32((bf16_t)(pk.x & 0xffff)); v.y += bf16_to_f32((bf16_t)(pk.x >> 16));
+    v.z += bf16_to_f32((bf16_t)(pk.y & 0xffff)); v.w += bf16_to_f32((bf16_t)(pk.y >> 16));
+    *d = v;
+  }
+}
+
 // y = x / max(||x||_2, eps) over the last dim; one wave per row; x fp32 -> y fp32 and/or bf16, saves 1/norm
 __global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, float* y, bf16_t* y16, float* inv_norm,
                                                           int M, int C, float eps) {
@@ -216,6 +238,16 @@ extern "C" int lc2is_sr_gather(const void* src_bf16, void* dst_bf16, int B, int 
   else
     hipLaunchKernelGGL(sr_gather_kernel<false>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)src_bf16,
                        (bf16_t*)dst_bf16, B, h, w, C);
+  return lc2is_check_launch();
+}
+
+extern "C" int lc2is_sr_scatter_add_f32(const void* src_bf16, float* dst_f32, int B, int h, int w, int C,
+                                        lc2is_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!src_bf16 || !dst_f32) return LC2IS_ERR_NULL;
+  if (B <= 0 || h <= 0 || w <= 0 || (h & 1) || (w & 1) || C <= 0 || C % 4) return LC2IS_ERR_SHAPE;
+  hipLaunchKernelGGL(sr_scatter_add_kernel, dim3(sp_grid((size_t)B * h * w * C / 4)), dim3(256), 0, stream,
+                     (const bf16_t*)src_bf16, dst_f32, B, h, w, C);
   return lc2is_check_launch();
 }
 

@@ -47,6 +47,7 @@ _ARGTYPES = {
     "lc2is_bilinear_up_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "lc2is_bilinear_up_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "lc2is_sr_gather": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "lc2is_sr_scatter_add_f32": [_P, _P, _I, _I, _I, _I, _P],
     "lc2is_l2norm_fwd": [_P, _P, _P, _P, _I, _I, _F, _P],
     "lc2is_l2norm_bwd": [_P, _P, _P, _P, _I, _I, _F, _P],
     "lc2is_add_n": [_P, _P, _P, _P, _P, _P, _Z, _P],
@@ -541,3 +542,10 @@ def add_n(tensors, *, want_f32: bool = True, want_bf16: bool = False):
     ob = torch.empty(tensors[0].shape, dtype=torch.bfloat16, device=tensors[0].device) if want_bf16 else None
     _lib.check(_fn("lc2is_add_n")(*ps, _ptr(of), _ptr(ob), tensors[0].numel(), _stream()), "add_n")
     return of, ob
+
+
+def sr_scatter_add(src16, dst32, B: int, h: int, w: int):
+    """dst32 [B*h*w, C] fp32 += scatter(src16 [B*h*w/4, 4C] bf16)."""
+    _dense(src16, torch.bfloat16, "src"); _dense(dst32, torch.float32, "dst")
+    Cc = dst32.shape[1]
+    _lib.check(_fn("lc2is_sr_scatter_add_f32")(_ptr(src16), _ptr(dst32), B, h, w, Cc, _stream()), "sr_scatter_add")
