@@ -7,8 +7,9 @@ from .hier import (CrossABlock, FTNBlock, FTNDecoder, HierarchicalCrossA, Hierar
                    SRTransformerCrossA, SRTransformerDecoder, SRTransformerSelfA)
 from .loss import AuxiliaryLoss, CrossEntropyLoss
 from .model import BaseModelWithText, TextToPatch
+from .score import ScoreMapTail
 
 __all__ = ["HipModule", "ParamArena", "ClipArch", "ImageEncoderCLIP", "ImageEncoderCLIPFull", "TextEncoderCLIP",
            "TextEncoderCLIPPooler", "DecoderBlock", "DecoderLayer", "AuxiliaryLoss", "CrossEntropyLoss",
-           "BaseModelWithText", "TextToPatch", "CrossABlock", "FTNBlock", "FTNDecoder", "HierarchicalCrossA",
+           "BaseModelWithText", "TextToPatch", "ScoreMapTail", "CrossABlock", "FTNBlock", "FTNDecoder", "HierarchicalCrossA",
            "HierarchicalSelfA", "SelfABlock", "SRTransformerCrossA", "SRTransformerDecoder", "SRTransformerSelfA", "VIT_B16", "VIT_L14", "TEXT_B", "TEXT_L"]

@@ -103,3 +103,23 @@ def test_ftn_decoder_and_blocks_vs_oracle(dev):
     with torch.no_grad():
         outb = blk(x.to(dev), mem.to(dev))
     assert outb.shape == (2, 256, 128) and _rel(outb, refb) < 1.5e-2
+
+
+def test_score_map_tail_vs_reference(dev):
+    import lc2is_amd.nn as N
+    t = torch.load(G / "hier_tiny.pt", weights_only=True)["tail"]
+    tail = N.ScoreMapTail(4)
+    ve = t["ve"].to(dev).requires_grad_(True)
+    te = t["te"].to(dev).requires_grad_(True)
+    sm = tail(ve, te)
+    assert sm.shape == t["score"].shape and (sm.cpu() - t["score"]).abs().max().item() < 1e-2   # cosine scores in [-1,1]
+    loss = tail.loss(ve, te, t["labels"].to(dev))
+    assert abs(loss.item() - t["loss"].item()) < 2e-3
+    loss.backward()
+    assert _rel(ve.grad, t["dve"]) < 3e-2 and _rel(te.grad, t["dte"]) < 3e-2
+    # unfused: materialised map -> CrossEntropyLoss -> backward gives the same gradients
+    ve2 = t["ve"].to(dev).requires_grad_(True)
+    te2 = t["te"].to(dev).requires_grad_(True)
+    l2 = N.CrossEntropyLoss()(tail(ve2, te2), t["labels"].to(dev))
+    l2.backward()
+    assert abs(l2.item() - loss.item()) < 1e-4 and _rel(ve2.grad, ve.grad) < 1e-2 and _rel(te2.grad, te.grad) < 1e-2
