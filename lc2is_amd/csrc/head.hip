@@ -200,16 +200,20 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_ce_kernel(HeadArgs p) {
   }
 }
 
-// ---- fast path: bicubic, S == 4 (the headline configuration) ------------------------------------------
+// ---- fast path: S == 4, bicubic (the headline configuration) or bilinear (config-5 score map, AuxiliaryLoss) ----
 // For S = 4 the output pixels Y in [4a+2, 4a+6) share one tap row set {a-1..a+2} and differ only in the
 // fractional weights t in {1/8, 3/8, 5/8, 7/8}.  Tiles are shifted by 2 pixels so they hold exactly 4x4 such
 // groups; a wave loads a group's 4x4 low-res cells into REGISTERS once (48 values per lane, lanes = channels),
 // evaluates its 16 pixels with separable row/column mixes, accumulates the gradient for the 16 cells in
 // registers, and touches LDS only for the final 48 adds per group (16x fewer LDS reads / atomics than the
 // generic kernel).
-constexpr int F4 = 7;  // footprint edge: 4 groups + 3
-
+// Bilinear uses the same grouping with 2 taps {a, a+1} and weights {1-t, t}; torch's clamp of the source
+// coordinate at 0 equals clamping the tap indices because the two clamped taps then coincide.
+template <int MODE>
 __global__ __launch_bounds__(HEAD_THREADS) void head_ce_s4_kernel(HeadArgs p) {
+  constexpr int NT = (MODE == LC2IS_INTERP_BICUBIC) ? 4 : 2;   // taps per axis
+  constexpr int OFF = (MODE == LC2IS_INTERP_BICUBIC) ? 1 : 0;  // first tap = a - OFF
+  constexpr int F4 = 4 + NT - 1;                               // footprint edge: 4 groups + NT - 1
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int tiles_x = (p.W + 2 + HT - 1) / HT, tiles_y = (p.H + 2 + HT - 1) / HT;
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_ce_s4_kernel(HeadArgs p) {
   const int fsize = F4 * F4 * Cp;
   for (int i = tid * 4; i < fsize; i += HEAD_THREADS * 4) {
     const int cell = i / Cp, c = i % Cp;
-    int ry = a0 - 1 + cell / F4, rx = b0 - 1 + cell % F4;
+    int ry = a0 - OFF + cell / F4, rx = b0 - OFF + cell % F4;
     ry = ry < 0 ? 0 : (ry > p.h - 1 ? p.h - 1 : ry);
     rx = rx < 0 ? 0 : (rx > p.w - 1 ? p.w - 1 : rx);
     *reinterpret_cast<float4*>(s_lo + i) =
@@ -230,11 +234,15 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_ce_s4_kernel(HeadArgs p) {
     if (p.dlo) *reinterpret_cast<float4*>(s_dlo + i) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   // weights of the four phases (identical for rows and columns)
-  float wt[4][4];
+  float wt[4][NT];
 #pragma unroll
   for (int ph = 0; ph < 4; ++ph) {
     const float t = 0.125f + 0.25f * (float)ph;
-    wt[ph][0] = cubic2(t + 1.f); wt[ph][1] = cubic1(t); wt[ph][2] = cubic1(1.f - t); wt[ph][3] = cubic2(2.f - t);
+    if constexpr (NT == 4) {
+      wt[ph][0] = cubic2(t + 1.f); wt[ph][1] = cubic1(t); wt[ph][2] = cubic1(1.f - t); wt[ph][3] = cubic2(2.f - t);
+    } else {
+      wt[ph][0] = 1.f - t; wt[ph][1] = t;
+    }
   }
   __syncthreads();
 
@@ -257,11 +265,11 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_ce_s4_kernel(HeadArgs p) {
     const int gi = 2 * wid + g2, gy = gi >> 2, gx = gi & 3;
     const int Yb = 4 * (a0 + gy) + 2, Xb = 4 * (b0 + gx) + 2;
     if (Yb >= p.H || Xb >= p.W || Yb + 3 < 0 || Xb + 3 < 0) continue;  // wave-uniform
-    float v[4][4][3], dacc[4][4][3];
+    float v[NT][NT][3], dacc[NT][NT][3];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < NT; ++j) {
         const float* cp = s_lo + ((gy + i) * F4 + gx + j) * Cp + lane;
         v[i][j][0] = cp[0]; v[i][j][1] = cp[64]; v[i][j][2] = cp[128];
         dacc[i][j][0] = 0.f; dacc[i][j][1] = 0.f; dacc[i][j][2] = 0.f;
@@ -269,12 +277,15 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_ce_s4_kernel(HeadArgs p) {
 #pragma unroll
     for (int py = 0; py < 4; ++py) {
       const int Y = Yb + py;
-      float r[4][3], tq[4][3];
+      float r[NT][3], tq[NT][3];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-          r[j][k] = wt[py][0] * v[0][j][k] + wt[py][1] * v[1][j][k] + wt[py][2] * v[2][j][k] + wt[py][3] * v[3][j][k];
+          float acc_r = 0.f;
+#pragma unroll
+          for (int i = 0; i < NT; ++i) acc_r += wt[py][i] * v[i][j][k];
+          r[j][k] = acc_r;
           tq[j][k] = 0.f;
         }
       if (Y >= 0 && Y < p.H) {
@@ -284,8 +295,12 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_ce_s4_kernel(HeadArgs p) {
           if (X < 0 || X >= p.W) continue;  // wave-uniform
           float lg[3];
 #pragma unroll
-          for (int k = 0; k < 3; ++k)
-            lg[k] = wt[px][0] * r[0][k] + wt[px][1] * r[1][k] + wt[px][2] * r[2][k] + wt[px][3] * r[3][k];
+          for (int k = 0; k < 3; ++k) {
+            float acc_l = 0.f;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc_l += wt[px][j] * r[j][k];
+            lg[k] = acc_l;
+          }
           if (p.hi_out) {
             const size_t plane = (size_t)p.H * p.W;
             float* o = p.hi_out + ((size_t)b * p.C) * plane + (size_t)Y * p.W + X;
@@ -313,23 +328,23 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_ce_s4_kernel(HeadArgs p) {
             for (int k = 0; k < 3; ++k) {
               const float gk = e[k] * inv - ((lsel == k && lane == llane) ? p.gscale : 0.f);
 #pragma unroll
-              for (int j = 0; j < 4; ++j) tq[j][k] += wt[px][j] * gk;
+              for (int j = 0; j < NT; ++j) tq[j][k] += wt[px][j] * gk;
             }
           }
         }
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
           for (int k = 0; k < 3; ++k) dacc[i][j][k] += wt[py][i] * tq[j][k];
     }
     if (p.dlo) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NT; ++j) {
           float* cp = s_dlo + ((gy + i) * F4 + gx + j) * Cp + lane;
           if (c_ok[0]) lds_add(cp, dacc[i][j][0]);
           if (c_ok[1]) lds_add(cp + 64, dacc[i][j][1]);
@@ -347,7 +362,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_ce_s4_kernel(HeadArgs p) {
     for (int i = tid; i < fsize; i += HEAD_THREADS) {
       const int cell = i / Cp, c = i % Cp;
       if (c >= p.C) continue;
-      int ry = a0 - 1 + cell / F4, rx = b0 - 1 + cell % F4;
+      int ry = a0 - OFF + cell / F4, rx = b0 - OFF + cell % F4;
       ry = ry < 0 ? 0 : (ry > p.h - 1 ? p.h - 1 : ry);
       rx = rx < 0 ? 0 : (rx > p.w - 1 ? p.w - 1 : rx);
       const float val = s_dlo[i];
@@ -486,17 +501,24 @@ extern "C" int lc2is_head_upsample_ce(const float* scores_lo, int ld, const int6
       return LC2IS_ERR_LAUNCH;
     attr_set = true;
   }
-  if (mode == LC2IS_INTERP_BICUBIC && S == 4) {
+  if (S == 4) {
     static bool attr4 = false;
-    const int lds4 = 2 * F4 * F4 * ld * (int)sizeof(float);
+    const int f4 = (mode == LC2IS_INTERP_BICUBIC) ? 7 : 5;
+    const int lds4 = 2 * f4 * f4 * ld * (int)sizeof(float);
     if (!attr4) {
-      if (hipFuncSetAttribute((const void*)head_ce_s4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              2 * F4 * F4 * CMAX * (int)sizeof(float)) != hipSuccess)
+      const int mx4 = 2 * 7 * 7 * CMAX * (int)sizeof(float);
+      if (hipFuncSetAttribute((const void*)head_ce_s4_kernel<LC2IS_INTERP_BICUBIC>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, mx4) != hipSuccess ||
+          hipFuncSetAttribute((const void*)head_ce_s4_kernel<LC2IS_INTERP_BILINEAR>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, mx4) != hipSuccess)
         return LC2IS_ERR_LAUNCH;
       attr4 = true;
     }
     const int t4 = ((H + 2 + HT - 1) / HT) * ((W + 2 + HT - 1) / HT);
-    hipLaunchKernelGGL(head_ce_s4_kernel, dim3(B * t4), dim3(HEAD_THREADS), lds4, stream, a);
+    if (mode == LC2IS_INTERP_BICUBIC)
+      hipLaunchKernelGGL(head_ce_s4_kernel<LC2IS_INTERP_BICUBIC>, dim3(B * t4), dim3(HEAD_THREADS), lds4, stream, a);
+    else
+      hipLaunchKernelGGL(head_ce_s4_kernel<LC2IS_INTERP_BILINEAR>, dim3(B * t4), dim3(HEAD_THREADS), lds4, stream, a);
     return lc2is_check_launch();
   }
   const int tiles = ((H + HT - 1) / HT) * ((W + HT - 1) / HT);

@@ -125,7 +125,8 @@ def test_optimizers(dev):
 
 @pytest.mark.parametrize("B,h,C,S,mode", [(2, 32, 151, 4, "bicubic"), (1, 8, 151, 4, "bicubic"),
                                           (2, 8, 150, 16, "bilinear"), (1, 16, 37, 8, "bilinear"),
-                                          (1, 12, 151, 4, "bicubic")])
+                                          (1, 12, 151, 4, "bicubic"), (2, 32, 150, 4, "bilinear"),
+                                          (1, 5, 150, 4, "bilinear"), (1, 8, 10, 4, "bilinear")])
 def test_head_upsample_ce(dev, B, h, C, S, mode):
     from lc2is_amd import ops
     g = torch.Generator(device="cpu").manual_seed(h + C)

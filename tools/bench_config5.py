@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[4] on one MI355X: the multi-scale decoder path on synthetic Swin-small stage tensors
+(SURVEY.md §8d config 5): HierarchicalCrossA(in_dims=[96,192,384,768], depth=[1,1,1], dim=512, nhead=8, dropout=0)
++ score-map tail (normalize, einsum, bilinear x4) + CE at 512x512, forward + backward + SGD.
+Prints one JSON line; `--profile-tail` additionally times the fused tail kernel alone (HBM roofline)."""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch
+
+import lc2is_amd.nn as N
+from lc2is_amd import ops
+from lc2is_amd.step import ParamArena
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--classes", type=int, default=150)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    B, K = args.batch, args.classes
+    torch.manual_seed(5)
+    dec = N.HierarchicalCrossA([96, 192, 384, 768], [1, 1, 1], 512, nhead=8, dropout=0).to(dev).train()
+    tail = N.ScoreMapTail(4)
+    arena = ParamArena(dec)
+    g = torch.Generator().manual_seed(5)
+    visual = [torch.randn(B, p, c, generator=g).to(dev) for p, c in zip((16384, 4096, 1024, 256), (96, 192, 384, 768))]
+    text = torch.randn(B, K, 512, generator=g).to(dev).requires_grad_(True)
+    labels = torch.randint(0, K, (B, 512, 512), generator=g).to(dev)
+
+    def step():
+        arena.zero_grad(set_to_none=True)
+        text.grad = None
+        emb = dec(visual, text)
+        loss = tail.loss(emb, text, labels)
+        loss.backward()
+        arena.finalize_grads()
+        ops.sgd_step(arena.flat, arena.grad, None, 1e-5)
+        for m in dec.modules():
+            if isinstance(m, N.HipModule):
+                m.invalidate_shadows()
+        return loss
+
+    for _ in range(args.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    # the fused tail kernel alone: reads [B,128,128,192] fp32 scores + int64 labels, writes the same-size gradient
+    scores = torch.randn(B * 16384, 192, device=dev)
+    for _ in range(2):
+        ops.head_upsample_ce(scores, labels, B, 128, 128, K, 4, ops.INTERP_BILINEAR, want_grad=True)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        ops.head_upsample_ce(scores, labels, B, 128, 128, K, 4, ops.INTERP_BILINEAR, want_grad=True)
+    e1.record()
+    torch.cuda.synchronize()
+    t_tail = e0.elapsed_time(e1) / 5 * 1e-3
+    alg_bytes = B * (16384 * 192 * 4 * 2 + 512 * 512 * 8)   # scores read + gradient write + labels
+    ref_bytes = B * (K * 512 * 512 * 4) * 2                  # what the reference materialises: fp32 map write + read for CE
+    print(json.dumps({
+        "workload": "config5: HierarchicalCrossA + score-map tail + CE @512x512 on synthetic Swin-small stages",
+        "batch": B, "images_per_s": B / dt, "ms_per_step": dt * 1e3, "loss": float(loss.item()),
+        "params_M": round(sum(p.numel() for p in dec.parameters()) / 1e6, 2),
+        "tail_kernel": {"us": t_tail * 1e6, "algorithmic_GBps": alg_bytes / t_tail / 1e9, "peak_GBps": 8000,
+                        "frac": alg_bytes / t_tail / 8e12, "bytes_algorithmic": alg_bytes,
+                        "bytes_reference_materialised_map": ref_bytes}}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
