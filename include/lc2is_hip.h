@@ -206,6 +206,25 @@ int lc2is_l2norm_bwd(const float* dy, const float* x, const float* inv_norm, flo
 int lc2is_add_n(const float* a, const float* b, const float* c, const float* d, float* out_f32, void* out_bf16,
                 size_t n, lc2is_stream_t stream);
 
+/* ---- remaining losses (model/loss.py) and the parity metric (metrics.py) on channels-last scores ----------
+ * rows_ce: softmax-CE over the K contiguous classes of each of M rows: loss_sum[0] += sum of per-row losses,
+ *   lse[M] (optional), dx (optional) (+)= grad_scale * (softmax - onehot).  ContrastiveLoss.loss_visual
+ *   (model/loss.py:59) — also usable for any [M,K] logits.
+ * cols_ce: ContrastiveLoss.loss_textual (model/loss.py:58): x viewed [B,H,W,K], log-softmax over H (dim 1 — what
+ *   nn.CrossEntropyLoss does with the reference's one-hot float targets), loss_sum[0] += sum over (b,w,k) columns;
+ *   dx += grad_scale * d/dx. */
+int lc2is_rows_ce(const float* x, const int64_t* labels, float* lse, float* loss_sum, float* dx, float grad_scale,
+                  int M, int K, int accumulate_dx, lc2is_stream_t stream);
+int lc2is_cols_ce(const float* x, const int64_t* labels, float* loss_sum, float* dx, float grad_scale, int B, int H,
+                  int W, int K, lc2is_stream_t stream);
+/* NPairLoss.forward before its reduction (model/loss.py:30-35): res[i] = sum_p pos_ip / (pos_ip + sum_q neg_iq). */
+int lc2is_npair(const float* x, const float* x_pos, const float* x_neg, float* res, int n, int n_pos, int n_neg, int d,
+                lc2is_stream_t stream);
+/* compute_mIOU's confusion counts (metrics.py:82-102): counts[b] = {intersection[K], predicted[K], labelled[K]} (int32,
+ * caller-zeroed) from NCHW scores at the upsampled size and the nearest-x S labels. */
+int lc2is_miou_counts(const float* scores_hi, const int64_t* labels_lo, int* counts, int B, int K, int H, int W, int S,
+                      lc2is_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -2,14 +2,14 @@
 from .base import HipModule, ParamArena
 from .clip import (ClipArch, ImageEncoderCLIP, ImageEncoderCLIPFull, TextEncoderCLIP, TextEncoderCLIPPooler,
                    TEXT_B, TEXT_L, VIT_B16, VIT_L14)
-from .decoder import DecoderBlock, DecoderLayer
+from .decoder import DecoderBlock, DecoderLayer, PromptDecoder, PromptLayer
 from .hier import (CrossABlock, FTNBlock, FTNDecoder, HierarchicalCrossA, HierarchicalSelfA, SelfABlock,
                    SRTransformerCrossA, SRTransformerDecoder, SRTransformerSelfA)
-from .loss import AuxiliaryLoss, CrossEntropyLoss
+from .loss import AuxiliaryLoss, ContrastiveLoss, CrossEntropyLoss, NPairLoss
 from .model import BaseModelWithText, TextToPatch
 from .score import ScoreMapTail
 
 __all__ = ["HipModule", "ParamArena", "ClipArch", "ImageEncoderCLIP", "ImageEncoderCLIPFull", "TextEncoderCLIP",
-           "TextEncoderCLIPPooler", "DecoderBlock", "DecoderLayer", "AuxiliaryLoss", "CrossEntropyLoss",
+           "TextEncoderCLIPPooler", "DecoderBlock", "DecoderLayer", "PromptDecoder", "PromptLayer", "AuxiliaryLoss", "ContrastiveLoss", "CrossEntropyLoss", "NPairLoss",
            "BaseModelWithText", "TextToPatch", "ScoreMapTail", "CrossABlock", "FTNBlock", "FTNDecoder", "HierarchicalCrossA",
            "HierarchicalSelfA", "SelfABlock", "SRTransformerCrossA", "SRTransformerDecoder", "SRTransformerSelfA", "VIT_B16", "VIT_L14", "TEXT_B", "TEXT_L"]

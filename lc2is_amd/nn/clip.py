@@ -220,6 +220,26 @@ def _remap_legacy_keys(state_dict, prefix, inner: str):
     state_dict.pop(prefix + "enc.embeddings.position_ids", None)
 
 
+def _interp_matrix_bicubic(n_in: int, n_out: int) -> torch.Tensor:
+    """U [n_out, n_in] of F.interpolate(mode="bicubic", size=n_out, align_corners=False): A = -0.75, border-clamped
+    taps (host-side, init-time only)."""
+    A = -0.75
+    c1 = lambda x: ((A + 2) * x - (A + 3)) * x * x + 1  # noqa: E731
+    c2 = lambda x: ((A * x - 5 * A) * x + 8 * A) * x - 4 * A  # noqa: E731
+    U = torch.zeros(n_out, n_in, dtype=torch.float64)
+    scale = n_in / n_out
+    for o in range(n_out):
+        src = scale * (o + 0.5) - 0.5
+        i0 = math.floor(src)
+        t = src - i0
+        for k, wgt in enumerate((c2(t + 1), c1(t), c1(1 - t), c2(2 - t))):
+            U[o, min(max(i0 - 1 + k, 0), n_in - 1)] += wgt
+    return U
+
+
+VIT_PRETRAINED_SIZE = 224  # model/encoder.py:9
+
+
 # ---- vision -------------------------------------------------------------------------------------------
 class _VisionFn(torch.autograd.Function):
     @staticmethod
@@ -257,8 +277,24 @@ class ImageEncoderCLIP(HipModule):
     def hidden_size(self) -> int:
         return self.arch.hidden
 
+    def pos_emebedding_interpolate(self, tgt_size: int, ignore_index: int = 1, weight: torch.Tensor | None = None) -> torch.Tensor:
+        """model/encoder.py:32-44 [sic]: 2-D bicubic resize of a position table trained at 224x224 (14x14 grid for
+        patch 16) to ``tgt_size`` x ``tgt_size``, first ``ignore_index`` rows (CLS) kept.  Init-time host code."""
+        w = (self.enc.embeddings.position_embedding.weight if weight is None else weight).detach().double().cpu()
+        old = VIT_PRETRAINED_SIZE // self.patch_size
+        keep, grid = w[:ignore_index], w[ignore_index:].reshape(old, old, -1)
+        U = _interp_matrix_bicubic(old, tgt_size)
+        new = torch.einsum("yi,ijc,xj->yxc", U, grid, U).reshape(tgt_size * tgt_size, -1)
+        return torch.cat([keep, new], dim=0).float()
+
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
         _remap_legacy_keys(state_dict, prefix, "vision_model")
+        # a pretrained 224x224 checkpoint: resize its position table like the reference ctor does (encoder.py:24-27)
+        key = prefix + "enc.embeddings.position_embedding.weight"
+        old_rows = (VIT_PRETRAINED_SIZE // self.patch_size) ** 2 + 1
+        mine = self.enc.embeddings.position_embedding.weight.shape[0]
+        if key in state_dict and state_dict[key].shape[0] == old_rows and mine != old_rows:
+            state_dict[key] = self.pos_emebedding_interpolate(self.in_size // self.patch_size, weight=state_dict[key])
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     def _build_shadows(self, device):

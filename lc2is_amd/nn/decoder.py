@@ -301,3 +301,18 @@ class DecoderBlock(HipModule):
         anchor = self.layers[0].norm1.weight
         save = torch.is_grad_enabled() and (anchor.requires_grad or tgt.requires_grad or memory.requires_grad)
         return _DecoderFn.apply(tgt, memory, anchor, self, memory_key_padding_mask, save)
+
+
+class PromptLayer(DecoderLayer):
+    """model/decoder.py:24-28: the same layer class with the reference's default dropout of 0.1 (so it only runs on
+    the HIP path in eval mode or when constructed with dropout=0)."""
+
+    def __init__(self, d_model: int, d_kv: int, nhead: int, dim_feedforward: int = 2048, dropout: float = 0.1,
+                 activation=torch.nn.functional.relu, layer_norm_eps: float = 0.00001, batch_first: bool = False,
+                 norm_first: bool = False, device=None, dtype=None, *, bias: bool = False) -> None:
+        super().__init__(d_model, d_kv, nhead, dim_feedforward, dropout, activation, layer_norm_eps, batch_first, norm_first,
+                         device, dtype, bias=bias)
+
+
+class PromptDecoder(DecoderBlock):
+    """model/decoder.py:30-33 (nn.TransformerDecoder with its default forward signature)."""

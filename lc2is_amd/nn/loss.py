@@ -77,3 +77,57 @@ class AuxiliaryLoss(CrossEntropyLoss):
         if input.shape[-2] != h or H != W or H % h or (H // h) not in (4, 8, 16) or input.shape[1] > 192:
             raise NotImplementedError("lc2is_amd AuxiliaryLoss: square maps, integer scale 4/8/16, <= 192 classes")
         return _AuxFn.apply(input, target, self.ignore_index, H // h)
+
+
+class _ContrastiveFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, outputs, labels, H):
+        B, HW, K = outputs.shape
+        W = HW // H
+        x = outputs.reshape(B * HW, K).float().contiguous()
+        lab = labels.reshape(B * HW).contiguous()
+        sums = torch.zeros(2, dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x)
+        ops.rows_ce(x, lab, loss_sum=sums[0:1], dx=dx, grad_scale=0.5 / (B * HW))
+        ops.cols_ce(x, lab, B, H, W, K, sums[1:2], dx=dx, grad_scale=0.5 / (B * W * K))
+        loss_visual = sums[0] / (B * HW)
+        loss_textual = sums[1] / (B * W * K)
+        ctx.dx, ctx.shape = dx, outputs.shape
+        ctx.mark_non_differentiable(loss_visual, loss_textual)
+        return (loss_textual + loss_visual) / 2, loss_visual, loss_textual
+
+    @staticmethod
+    def backward(ctx, g, _gv, _gt):
+        return (ctx.dx * g).view(ctx.shape), None, None
+
+
+class ContrastiveLoss(nn.Module):
+    """Drop-in for model/loss.py:39-64.  outputs [B,HW,K], labels [B,H,W] -> (mean, loss_visual, loss_textual);
+    the textual term reproduces nn.CrossEntropyLoss on a [B,H,W,K] input with one-hot float targets (class axis =
+    dim 1, i.e. a softmax over image rows), exactly what the reference computes."""
+
+    def __init__(self, weight=None, size_average=None, ignore_index: int = -100, reduce=None, reduction: str = "mean",
+                 label_smoothing: float = 0) -> None:
+        super().__init__()
+        if weight is not None or reduction != "mean" or label_smoothing != 0:
+            raise NotImplementedError("lc2is_amd ContrastiveLoss: default CrossEntropyLoss configuration only")
+
+    def forward(self, outputs: torch.Tensor, labels: torch.Tensor):
+        require_cuda(outputs, "outputs")
+        H = int(round(outputs.shape[1] ** 0.5))
+        if outputs.shape[2] != 151:
+            raise ValueError("ContrastiveLoss: the reference hard-codes num_classes=151 (model/loss.py:55)")
+        return _ContrastiveFn.apply(outputs, labels, H)
+
+
+class NPairLoss(nn.Module):
+    """Drop-in for model/loss.py:23-37 (forward only on the HIP path; the loss is unused by every composition)."""
+
+    def __init__(self, reduction=torch.mean) -> None:
+        super().__init__()
+        self.reduction = reduction
+
+    def forward(self, x: torch.Tensor, x_pos: torch.Tensor, x_neg: torch.Tensor):
+        require_cuda(x, "x")
+        res = ops.npair(x.float().contiguous(), x_pos.float().contiguous(), x_neg.float().contiguous())
+        return self.reduction(res) if self.reduction else res

@@ -51,6 +51,10 @@ _ARGTYPES = {
     "lc2is_l2norm_fwd": [_P, _P, _P, _P, _I, _I, _F, _P],
     "lc2is_l2norm_bwd": [_P, _P, _P, _P, _I, _I, _F, _P],
     "lc2is_add_n": [_P, _P, _P, _P, _P, _P, _Z, _P],
+    "lc2is_rows_ce": [_P, _P, _P, _P, _P, _F, _I, _I, _I, _P],
+    "lc2is_cols_ce": [_P, _P, _P, _P, _F, _I, _I, _I, _I, _P],
+    "lc2is_npair": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "lc2is_miou_counts": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
 }
 _bound = {}
 
@@ -549,3 +553,36 @@ def sr_scatter_add(src16, dst32, B: int, h: int, w: int):
     _dense(src16, torch.bfloat16, "src"); _dense(dst32, torch.float32, "dst")
     Cc = dst32.shape[1]
     _lib.check(_fn("lc2is_sr_scatter_add_f32")(_ptr(src16), _ptr(dst32), B, h, w, Cc, _stream()), "sr_scatter_add")
+
+
+def rows_ce(x, labels, *, loss_sum=None, dx=None, grad_scale: float = 1.0, accumulate_dx: bool = False, want_lse=False):
+    _dense(x, torch.float32, "x")
+    M, K = x.shape
+    lse = torch.empty((M,), dtype=torch.float32, device=x.device) if want_lse else None
+    _lib.check(_fn("lc2is_rows_ce")(_ptr(x), _ptr(labels), _ptr(lse), _ptr(loss_sum), _ptr(dx), grad_scale, M, K,
+                                    int(accumulate_dx), _stream()), "rows_ce")
+    return lse
+
+
+def cols_ce(x, labels, B: int, H: int, W: int, K: int, loss_sum, dx=None, grad_scale: float = 1.0):
+    _dense(x, torch.float32, "x")
+    _lib.check(_fn("lc2is_cols_ce")(_ptr(x), _ptr(labels), _ptr(loss_sum), _ptr(dx), grad_scale, B, H, W, K, _stream()),
+               "cols_ce")
+
+
+def npair(x, x_pos, x_neg):
+    for t, n in ((x, "x"), (x_pos, "x_pos"), (x_neg, "x_neg")):
+        _dense(t, torch.float32, n)
+    res = torch.empty((x.shape[0],), dtype=torch.float32, device=x.device)
+    _lib.check(_fn("lc2is_npair")(_ptr(x), _ptr(x_pos), _ptr(x_neg), _ptr(res), x.shape[0], x_pos.shape[0],
+                                  x_neg.shape[0], x.shape[1], _stream()), "npair")
+    return res
+
+
+def miou_counts(scores_hi, labels_lo, S: int):
+    _chk(scores_hi, torch.float32, "scores_hi", 4); _chk(labels_lo, torch.int64, "labels", 3)
+    B, K, H, W = scores_hi.shape
+    counts = torch.zeros((B, 3, K), dtype=torch.int32, device=scores_hi.device)
+    _lib.check(_fn("lc2is_miou_counts")(_ptr(scores_hi.contiguous()), _ptr(labels_lo.contiguous()), _ptr(counts), B, K, H,
+                                        W, S, _stream()), "miou_counts")
+    return counts

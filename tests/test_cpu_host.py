@@ -82,3 +82,22 @@ def test_product_has_no_cpu_path_and_never_imports_the_oracle():
     for f in (ROOT / "lc2is_amd").rglob("*.py"):
         text = f.read_text()
         assert "import oracle" not in text and "from oracle" not in text, f
+
+
+def test_pos_embedding_interpolation_matches_reference_vector():
+    """ImageEncoderCLIP.pos_emebedding_interpolate (model/encoder.py:32-44) and the load-time resize of a 224x224 table."""
+    import lc2is_amd.nn as N
+    fx = torch.load(G / "ops.pt", weights_only=True)
+    enc = N.ImageEncoderCLIP(128, 16, arch=N.ClipArch(32, 1, 1, 64))
+    out = enc.pos_emebedding_interpolate(8, weight=fx["posint_in"])
+    assert torch.allclose(out, fx["posint_out"], atol=1e-5)
+    sd = enc.state_dict()
+    sd["enc.embeddings.position_embedding.weight"] = fx["posint_in"]          # 197 rows, as in a hub checkpoint
+    enc.load_state_dict(sd, strict=True)
+    assert torch.allclose(enc.enc.embeddings.position_embedding.weight, fx["posint_out"], atol=1e-5)
+
+
+def test_prompt_aliases_exist():
+    import lc2is_amd.nn as N
+    layer = N.PromptLayer(d_model=128, d_kv=256, nhead=2, batch_first=True)
+    assert layer.dropout_p == 0.1 and isinstance(N.PromptDecoder(layer, 2), N.DecoderBlock)

@@ -185,3 +185,33 @@ def test_no_cpu_fallback():
     enc = N.TextEncoderCLIP(16, arch=N.ClipArch(64, 1, 1, 128, vocab=300, eos_token_id=299))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         enc(torch.zeros(1, 4, dtype=torch.int64), torch.ones(1, 4, dtype=torch.int64))
+
+
+def test_contrastive_npair_losses_vs_reference(dev):
+    import lc2is_amd.nn as N
+    fx = torch.load(G / "ops.pt", weights_only=True)
+    out = fx["con_in"].to(dev).requires_grad_(True)
+    total, lv, lt = N.ContrastiveLoss()(out, fx["ce_labels"].to(dev))
+    got = torch.stack([total, lv, lt]).cpu()
+    assert torch.allclose(got, fx["con"], atol=1e-5), (got, fx["con"])
+    total.backward()
+    from oracle import ref_cpu as O
+    x = fx["con_in"].clone().requires_grad_(True)
+    O.contrastive_loss(x, fx["ce_labels"])[0].backward()
+    assert _rel(out.grad, x.grad) < 1e-4
+    r = N.NPairLoss()(fx["np_x"].to(dev), fx["np_pos"].to(dev), fx["np_neg"].to(dev))
+    assert abs(r.item() - fx["npair"].item()) < 1e-4 * max(1.0, abs(fx["npair"].item()))
+
+
+def test_device_miou_vs_oracle(dev):
+    """metrics.compute_mIOU needs torchmetrics (absent): checked against the oracle's restatement (parity unpinned)."""
+    from lc2is_amd.metrics import compute_mIOU
+    from oracle import ref_cpu as O
+    g = torch.Generator().manual_seed(4)
+    labels = torch.randint(0, 151, (3, 16, 16), generator=g)
+    labels = labels[:, ::4, ::4].repeat_interleave(4, 1).repeat_interleave(4, 2)      # 4x4-block-constant (SURVEY §8d)
+    logits = torch.randn(3, 151, 16, 16, generator=g)
+    logits.scatter_add_(1, labels.unsqueeze(1), torch.full((3, 1, 16, 16), 3.0))
+    ref = O.compute_miou(logits, labels)
+    got = compute_mIOU(logits.to(dev), labels.to(dev))["mIOU_label"]
+    assert abs(got - ref) < 1e-3, (got, ref)
