@@ -215,3 +215,36 @@ def test_device_miou_vs_oracle(dev):
     ref = O.compute_miou(logits, labels)
     got = compute_mIOU(logits.to(dev), labels.to(dev))["mIOU_label"]
     assert abs(got - ref) < 1e-3, (got, ref)
+
+
+def test_config4_vit_l14_640_shapes_vs_oracle(dev):
+    """BASELINE configs[3] geometry at reduced depth: ViT-L/14 widths (1024, 16 heads), 640x640 (grid 45, 2026 tokens,
+    the conv drops the last 10 pixels), text width 768, decoder head_dim 128, output 180x180 — an extension with no
+    reference code path (model/encoder.py:18-21 only maps patch 16); parity is against the CPU oracle."""
+    import lc2is_amd.nn as N
+    from oracle import ref_cpu as O
+    torch.manual_seed(14)
+    m = N.BaseModelWithText(14, 640, 180, vision_arch=N.ClipArch(1024, 16, 1, 4096),
+                            text_arch=N.ClipArch(768, 12, 1, 3072, vocab=1000, eos_token_id=999), nhead=8)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(15)
+    B, L = 1, 8
+    inputs = dict(pixel_values=torch.randn(B, 3, 640, 640, generator=g), input_ids=torch.randint(1, 998, (B, L), generator=g),
+                  attention_mask=torch.ones(B, L, dtype=torch.int64))
+    inputs["input_ids"][:, -1] = 999
+    labels = torch.randint(0, 151, (B, 180, 180), generator=g)
+    cfg = O.BaseCfg(in_size=640, out_size=180, patch=14, vision=O.ClipCfg(1024, 16, 1, patch=14),
+                    text=O.ClipCfg(768, 12, 1, eos_token_id=999), dec_heads=8, dec_layers=1)
+    _, _, ref = O.base_model_with_text(sd, inputs, cfg)
+    ref_loss = O.cross_entropy(ref, labels)
+    m = m.to(dev).train()
+    dinputs = {k: v.to(dev) for k, v in inputs.items()}
+    with torch.no_grad():
+        out = m(dinputs)["outputs"]
+    assert out.shape == (B, 151, 180, 180)
+    assert _rel(out, ref) < 2e-2
+    loss = m.forward_loss(dinputs, labels.to(dev))
+    assert abs(loss.item() - ref_loss.item()) < 3e-2
+    loss.backward()
+    gsum = sum(float(p.grad.abs().sum()) for p in m.parameters() if p.grad is not None)
+    assert gsum > 0 and gsum == gsum
