@@ -523,6 +523,97 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmNtArgs p) {
     gemm_epilogue<TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lane);
 }
 
+// ---- ring variant: 4-deep LDS ring of 32-wide K slices, LDS-DMA kept 2-3 slices ahead ------------------------
+// PMC on the two-buffer kernel shows the matrix pipe busy only ~45 % with the waves parked at the per-tile barrier:
+// one K tile (~1 us) of lookahead does not cover the L2/MALL latency of the LDS-DMA under load.  Here the 256x256
+// tile is fed through FOUR 32 KiB stages (K slice = 32); the DMA for slice t+3 is issued right after the barrier
+// of slice t and waited with a COUNTED s_waitcnt vmcnt(8) (two younger slices stay in flight) — never vmcnt(0) in
+// the main loop.  64-byte LDS rows use the chunk swizzle  c ^= (-(row>>2)) & 3  (conflict-free for the
+// ds_read_b128 lane groups); accumulation order equals the other kernels' (bitwise-equal results).
+__global__ __launch_bounds__(512) void gemm_nt_ring_kernel(GemmNtArgs p) {
+  constexpr int BM = 256, BN = 256, WAVES_N = 4, BK = 32, NST = 4;
+  constexpr int WM = 128, WN = 64, TM = 8, TN = 4;
+  constexpr int PIECES = 2;               // 1-KiB pieces (16 rows x 64 B) per wave per operand per stage
+  constexpr int STAGE = (BM + BN) * 64;   // 32 KiB
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)LDS_PTR(smem);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+  const int ntn = (p.N + BN - 1) / BN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+
+  const int lrow = lane >> 2, lch = (lane & 3) ^ ((-(lane >> 4)) & 3);  // (row>>2)&3 == lane>>4 inside a 16-row piece
+  const char* a_src[PIECES];
+  const char* w_src[PIECES];
+#pragma unroll
+  for (int j = 0; j < PIECES; ++j) {
+    int ar = m0 + 16 * (wid * PIECES + j) + lrow;
+    int wr = n0 + 16 * (wid * PIECES + j) + lrow;
+    ar = ar < p.M ? ar : p.M - 1;
+    wr = wr < p.N ? wr : p.N - 1;
+    a_src[j] = (const char*)p.A + ((size_t)ar * p.lda + lch * 8) * 2;
+    w_src[j] = (const char*)p.W + ((size_t)wr * p.ldw + lch * 8) * 2;
+  }
+  const unsigned a_dst = lds_base + wid * PIECES * 1024;
+  const unsigned w_dst = lds_base + BM * 64 + wid * PIECES * 1024;
+
+#define RG_ISSUE(KT)                                                                        \
+  do {                                                                                      \
+    const int st_ = ((KT) & (NST - 1)) * STAGE;                                             \
+    const int kb_ = (KT)*BK * 2;                                                            \
+    _Pragma("unroll") for (int j = 0; j < PIECES; ++j) glds16(a_src[j] + kb_, a_dst + st_ + j * 1024); \
+    _Pragma("unroll") for (int j = 0; j < PIECES; ++j) glds16(w_src[j] + kb_, w_dst + st_ + j * 1024); \
+  } while (0)
+
+  f32x4_t acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, g = lane >> 4;
+  const int kc_off = ((g ^ ((-(frow >> 2)) & 3)) << 4);
+  const int x_frag = (wm * WM + frow) * 64 + kc_off;
+  const int w_frag = BM * 64 + (wn * WN + frow) * 64 + kc_off;
+  const int nk = p.K / BK;
+
+  RG_ISSUE(0);
+  if (nk > 1) RG_ISSUE(1);
+  if (nk > 2) RG_ISSUE(2);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    // this wave's pieces of slice kt have landed once at most the two younger slices (2 x 4 DMAs) are outstanding
+    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();   // every wave's pieces of slice kt are in LDS; all reads of slice kt-1 are done
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 3 < nk) RG_ISSUE(kt + 3);   // overwrites the stage read during iteration kt-1
+    const char* cur = smem + (kt & (NST - 1)) * STAGE;
+    bf16x8_t xf[TM], wf[TN];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) xf[j] = *(const bf16x8_t*)(cur + x_frag + j * 16 * 64);
+#pragma unroll
+    for (int i = 0; i < TN; ++i) wf[i] = *(const bf16x8_t*)(cur + w_frag + i * 16 * 64);
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+  }
+#undef RG_ISSUE
+  __syncthreads();
+  if (p.staged_epi)
+    gemm_epilogue_lds<TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lane, wid, smem);
+  else
+    gemm_epilogue<TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lane);
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 int launch_cfg(const GemmNtArgs& a, hipStream_t stream) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
@@ -552,6 +643,20 @@ int launch_dma(const GemmNtArgs& a, hipStream_t stream) {
   }
   const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
   hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(NT), LDS, stream, a);
+  return lc2is_check_launch();
+}
+
+int launch_ring(const GemmNtArgs& a, hipStream_t stream) {
+  constexpr int LDS = 4 * (256 + 256) * 64;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm_nt_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
+        hipSuccess)
+      return LC2IS_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int ntm = (a.M + 255) / 256, ntn = (a.N + 255) / 256;
+  hipLaunchKernelGGL(gemm_nt_ring_kernel, dim3(ntm * ntn), dim3(512), LDS, stream, a);
   return lc2is_check_launch();
 }
 
@@ -609,6 +714,7 @@ extern "C" int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw
     case 5: return launch_dma<256, 128, 4, 2>(a, stream);
     case 6: return launch_dma<128, 128, 2, 2>(a, stream);
     case 7: return launch_pp(a, stream);
+    case 8: return launch_ring(a, stream);
     default: return LC2IS_ERR_UNSUPPORTED;
   }
 }

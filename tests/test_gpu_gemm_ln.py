@@ -18,6 +18,7 @@ def _rel(a, b):
     (129, 152, 512, 0), (77, 64, 64, 3), (2050, 768, 3072, 2), (2050, 768, 3072, 4), (300, 192, 128, 4),
     (1025, 2304, 768, 5), (300, 192, 128, 5), (515, 384, 192, 6), (4100, 768, 768, 4),
     (2050, 768, 3072, 7), (300, 192, 128, 7), (4100, 768, 768, 7), (1025, 2304, 64, 7),
+    (2050, 768, 3072, 8), (300, 192, 128, 8), (4100, 768, 768, 8), (1025, 2304, 64, 8),
 ])
 def test_gemm_nt_plain(dev, M, N, K, cfg):
     from lc2is_amd import ops
@@ -42,7 +43,7 @@ def test_gemm_nt_asymmetric_identity(dev):
     assert torch.equal(of, w.float().T.contiguous())
 
 
-@pytest.mark.parametrize("cfg", [0, 4, 5, 6, 7])
+@pytest.mark.parametrize("cfg", [0, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("act", ["quick_gelu", "relu"])
 def test_gemm_nt_activation_and_backward_epilogue(dev, act, cfg):
     from lc2is_amd import ops
@@ -158,6 +159,7 @@ def test_gemm_nt_pingpong_is_bitwise_equal_to_simple_pipeline(dev):
         w = _bf(torch.randn(N, K, generator=g) * 0.05).to(dev)
         bias = torch.randn(N, generator=g).to(dev)
         ref, reff, _ = ops.gemm_nt(a, w, bias, out_bf16=True, out_f32=True, tile_cfg=4)
-        for _ in range(5):
-            ob, of, _ = ops.gemm_nt(a, w, bias, out_bf16=True, out_f32=True, tile_cfg=7)
-            assert torch.equal(of, reff) and torch.equal(ob, ref), (M, N, K)
+        for cfg in (7, 8):
+            for _ in range(5):
+                ob, of, _ = ops.gemm_nt(a, w, bias, out_bf16=True, out_f32=True, tile_cfg=cfg)
+                assert torch.equal(of, reff) and torch.equal(ob, ref), (M, N, K, cfg)
