@@ -292,13 +292,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmNtAr
   gemm_epilogue<TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lane);
 }
 
+// (the LDS-DMA builtin has to live in a __device__ helper that takes no __amdgpu_buffer_rsrc_t parameter: with the
+//  builtin in a __global__ body, or the opaque descriptor type in a template signature, hipcc's host pass drops the kernel stub)
 template <int BM, int A_PIECES, int W_PIECES>
-__device__ __forceinline__ void dma_stage(__amdgpu_buffer_rsrc_t rsA, __amdgpu_buffer_rsrc_t rsW, char* buf, int wid,
-                                          const int (&a_goff)[A_PIECES], const int (&w_goff)[W_PIECES], int kb) {
+__device__ __forceinline__ void dma_stage(const bf16_t* A, unsigned a_bytes, const bf16_t* W, unsigned w_bytes, char* buf,
+                                          int wid, const int* a_goff, const int* w_goff, int kb) {
+  const __amdgpu_buffer_rsrc_t rsA = make_rsrc(A, a_bytes);
+  const __amdgpu_buffer_rsrc_t rsW = make_rsrc(W, w_bytes);
 #pragma unroll
   for (int j = 0; j < A_PIECES; ++j)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(buf + (wid * A_PIECES + j) * 1024), 16, a_goff[j] + kb, 0,
-                                             0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(buf + (wid * A_PIECES + j) * 1024), 16, a_goff[j] + kb, 0, 0, 0);
 #pragma unroll
   for (int j = 0; j < W_PIECES; ++j)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_PTR(buf + BM * 128 + (wid * W_PIECES + j) * 1024), 16,
@@ -312,7 +315,9 @@ __device__ __forceinline__ void dma_stage(__amdgpu_buffer_rsrc_t rsA, __amdgpu_b
 // row l>>3) and the fragment reads use the same involution.  The DMA of tile t+1 is issued right after the
 // barrier that publishes tile t and flies during the MFMAs of tile t; the barrier's implicit vmcnt(0) retires
 // it.  256x256 tile, 8 waves (2x4), 128x64 per wave: 12 ds_read_b128 per 32 MFMAs.
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+// DBG (diagnostic builds only, tools/gemm_ablate.py; results are WRONG by design): bit 0 = no epilogue,
+// bit 1 = no LDS-DMA inside the K loop (tile 0 is reused), bit 2 = fragments read once before the loop.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int DBG = 0>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_dma_kernel(GemmNtArgs p) {
   constexpr int NWAVE = WAVES_M * WAVES_N;
   constexpr int BK = 64;
@@ -332,8 +337,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_dma_kernel(Gemm
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
 
-  const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, (unsigned)p.M * (unsigned)p.lda * 2u);
-  const __amdgpu_buffer_rsrc_t rsW = make_rsrc(p.W, (unsigned)p.N * (unsigned)p.ldw * 2u);
+  const unsigned a_bytes = (unsigned)p.M * (unsigned)p.lda * 2u, w_bytes = (unsigned)p.N * (unsigned)p.ldw * 2u;
 
   // per-lane source offsets of this wave's pieces (piece j of wave w = rows 8*(w*PIECES + j) .. +7)
   const int lrow = lane >> 3, lch = (lane & 7) ^ (lane >> 3);
@@ -358,22 +362,38 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_dma_kernel(Gemm
   const int kc_off0 = ((0 + g) ^ sw) << 4, kc_off1 = ((4 + g) ^ sw) << 4;
   const int nk = p.K / BK;
 
-  dma_stage<BM, A_PIECES, W_PIECES>(rsA, rsW, smem, wid, a_goff, w_goff, 0);
+  dma_stage<BM, A_PIECES, W_PIECES>(p.A, a_bytes, p.W, w_bytes, smem, wid, a_goff, w_goff, 0);
   __syncthreads();  // emits s_waitcnt vmcnt(0): tile 0 has landed for every wave
 
+  bf16x8_t xf0[TM], wf0[TN];
+  if constexpr ((DBG & 4) != 0) {
+#pragma unroll
+    for (int j = 0; j < TM; ++j) xf0[j] = *(const bf16x8_t*)(smem + x_frag + j * 16 * 128 + kc_off0);
+#pragma unroll
+    for (int i = 0; i < TN; ++i) wf0[i] = *(const bf16x8_t*)(smem + w_frag + i * 16 * 128 + kc_off0);
+  }
   for (int kt = 0; kt < nk; ++kt) {
     const char* cur = smem + (kt & 1) * STAGE;
-    if (kt + 1 < nk)
-      dma_stage<BM, A_PIECES, W_PIECES>(rsA, rsW, smem + ((kt + 1) & 1) * STAGE, wid, a_goff, w_goff,
-                                        (kt + 1) * BK * 2);
+    if constexpr ((DBG & 2) == 0) {
+      if (kt + 1 < nk)
+        dma_stage<BM, A_PIECES, W_PIECES>(p.A, a_bytes, p.W, w_bytes, smem + ((kt + 1) & 1) * STAGE, wid, a_goff, w_goff,
+                                          (kt + 1) * BK * 2);
+    }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int ko = ks ? kc_off1 : kc_off0;
       bf16x8_t xf[TM], wf[TN];
+      if constexpr ((DBG & 4) != 0) {
 #pragma unroll
-      for (int j = 0; j < TM; ++j) xf[j] = *(const bf16x8_t*)(cur + x_frag + j * 16 * 128 + ko);
+        for (int j = 0; j < TM; ++j) { xf[j] = xf0[j]; asm volatile("" : "+v"(xf[j])); }
 #pragma unroll
-      for (int i = 0; i < TN; ++i) wf[i] = *(const bf16x8_t*)(cur + w_frag + i * 16 * 128 + ko);
+        for (int i = 0; i < TN; ++i) { wf[i] = wf0[i]; asm volatile("" : "+v"(wf[i])); }
+      } else {
+#pragma unroll
+        for (int j = 0; j < TM; ++j) xf[j] = *(const bf16x8_t*)(cur + x_frag + j * 16 * 128 + ko);
+#pragma unroll
+        for (int i = 0; i < TN; ++i) wf[i] = *(const bf16x8_t*)(cur + w_frag + i * 16 * 128 + ko);
+      }
 #pragma unroll
       for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -381,6 +401,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_dma_kernel(Gemm
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();  // all reads of `cur` done; DMA of the next tile retired (vmcnt(0)) and published
+  }
+  if constexpr ((DBG & 1) != 0) {
+    float sacc = 0.f;  // keep the accumulators alive without the store traffic
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (sacc == 1.2345e30f && p.out_f32) p.out_f32[0] = sacc;
+    return;
   }
   if (p.staged_epi)
     gemm_epilogue_lds<TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lane, wid, smem);
@@ -630,11 +659,11 @@ int launch_cfg(const GemmNtArgs& a, hipStream_t stream) {
   return lc2is_check_launch();
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int DBG = 0>
 int launch_dma(const GemmNtArgs& a, hipStream_t stream) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int LDS = 2 * (BM + BN) * 128;
-  auto kern = gemm_nt_dma_kernel<BM, BN, WAVES_M, WAVES_N>;
+  auto kern = gemm_nt_dma_kernel<BM, BN, WAVES_M, WAVES_N, DBG>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
@@ -715,6 +744,12 @@ extern "C" int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw
     case 6: return launch_dma<128, 128, 2, 2>(a, stream);
     case 7: return launch_pp(a, stream);
     case 8: return launch_ring(a, stream);
+    // diagnostic ablations of cfg 4 (wrong results by design; tools/gemm_ablate.py only)
+    case 41: return launch_dma<256, 256, 2, 4, 1>(a, stream);
+    case 42: return launch_dma<256, 256, 2, 4, 2>(a, stream);
+    case 43: return launch_dma<256, 256, 2, 4, 3>(a, stream);
+    case 45: return launch_dma<256, 256, 2, 4, 5>(a, stream);
+    case 47: return launch_dma<256, 256, 2, 4, 7>(a, stream);
     default: return LC2IS_ERR_UNSUPPORTED;
   }
 }
