@@ -18,6 +18,7 @@
 // Block ids are remapped so that each XCD (private L2) owns a contiguous run of tiles.
 #include "common.h"
 #include "lc2is_hip.h"
+#include <cstdlib>
 
 namespace {
 
@@ -32,9 +33,10 @@ struct GemmNtArgs {
   bf16_t* aux_out; int ldy;
   int M, N, K, act;
   int staged_epi;  // bf16 epilogue traffic through LDS (needs N % 8 == 0 and 8-element-aligned leading dims)
+  int stagger;     // experiment: start-up delay (units of 64 clocks) of the second co-resident block
 };
 
-__device__ __forceinline__ float sigmoidf_fast(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float sigmoidf_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }  // v_exp + v_rcp
 
 template <int TM, int TN, int WM, int WN>
 __device__ __forceinline__ void gemm_epilogue(const GemmNtArgs& p, f32x4_t (&acc)[TN][TM], int m0, int n0, int wm,
@@ -156,7 +158,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmNtArgs& p, f32x4_t (
       for (int it = 0; it < 8; ++it) {
         const int r = it * 8 + srow, m = mrow0 + r;
         const i32x4_t v = *(const i32x4_t*)(patch + r * PITCH + sch * 16);
-        if (m < p.M && col_ok) *(i32x4_t*)(p.aux_out + (size_t)m * p.ldy + nw + sch * 8) = v;
+        if (m < p.M && col_ok) __builtin_nontemporal_store(v, (i32x4_t*)(p.aux_out + (size_t)m * p.ldy + nw + sch * 8));
       }
     }
     // ---- (D) activation, fp32 residual / output (direct), (E) bf16 output through the patch ----
@@ -176,7 +178,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmNtArgs& p, f32x4_t (
         }
         const bool ok = (m < p.M) && (n < p.N);
         if (p.resid && ok) v += *(const f32x4_t*)(p.resid + (size_t)m * p.ldr + n);
-        if (p.out_f32 && ok) *(f32x4_t*)(p.out_f32 + (size_t)m * p.ldf + n) = v;
+        if (p.out_f32 && ok) __builtin_nontemporal_store(v, (f32x4_t*)(p.out_f32 + (size_t)m * p.ldf + n));
         if (p.out_bf16) {
           i32x2_t pk = {(int)pack_bf16x2(v[0], v[1]), (int)pack_bf16x2(v[2], v[3])};
           *(i32x2_t*)(patch + (jl * 16 + frow) * PITCH + (i * 16 + g * 4) * 2) = pk;
@@ -188,7 +190,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmNtArgs& p, f32x4_t (
       for (int it = 0; it < 8; ++it) {
         const int r = it * 8 + srow, m = mrow0 + r;
         const i32x4_t v = *(const i32x4_t*)(patch + r * PITCH + sch * 16);
-        if (m < p.M && col_ok) *(i32x4_t*)(p.out_bf16 + (size_t)m * p.ldo + nw + sch * 8) = v;
+        if (m < p.M && col_ok) __builtin_nontemporal_store(v, (i32x4_t*)(p.out_bf16 + (size_t)m * p.ldo + nw + sch * 8));
       }
     }
   }
@@ -643,6 +645,103 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(GemmNtArgs p) {
     gemm_epilogue<TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lane);
 }
 
+// ---- duo variant: two co-resident 4-wave blocks per CU, each on a 256x128 tile ------------------------------
+// tools/gemm_ablate.py on the 256x256 kernel: the epilogue (bf16/fp32 stores, saved pre-activations) is 25-30 % of
+// the kernel and the matrix pipe idles through it, because the single 8-wave block of a CU is in its epilogue as a
+// whole.  Here a block is 4 waves (2x2, 128x64 per wave as before) on a 256x128 tile fed through a 3-deep ring of
+// 32-wide K slices (3 x 24 KiB = 72 KiB LDS), so TWO blocks fit a CU (2 waves/SIMD, 256 VGPRs each) and drift apart:
+// one block's epilogue, prologue and launch gap run under the other block's MFMA stream.  DMA for slice t+2 is issued
+// after the barrier of slice t and waited with a counted vmcnt (one younger slice stays in flight).  Accumulation
+// order per output element equals the other kernels' (bitwise-equal results).
+__global__ __launch_bounds__(256, 2) void gemm_nt_duo_kernel(GemmNtArgs p) {
+  constexpr int BM = 256, BN = 128, WAVES_N = 2, BK = 32, NST = 3;
+  constexpr int WM = 128, WN = 64, TM = 8, TN = 4;
+  constexpr int A_PIECES = 4, W_PIECES = 2;   // 1-KiB pieces (16 rows x 64 B) per wave per stage
+  constexpr int STAGE = (BM + BN) * 64;       // 24 KiB
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)LDS_PTR(smem);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+  const int ntn = (p.N + BN - 1) / BN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+
+  const int lrow = lane >> 2, lch = (lane & 3) ^ ((-(lane >> 4)) & 3);
+  const char* a_src[A_PIECES];
+  const char* w_src[W_PIECES];
+#pragma unroll
+  for (int j = 0; j < A_PIECES; ++j) {
+    int ar = m0 + 16 * (wid * A_PIECES + j) + lrow;
+    ar = ar < p.M ? ar : p.M - 1;
+    a_src[j] = (const char*)p.A + ((size_t)ar * p.lda + lch * 8) * 2;
+  }
+#pragma unroll
+  for (int j = 0; j < W_PIECES; ++j) {
+    int wr = n0 + 16 * (wid * W_PIECES + j) + lrow;
+    wr = wr < p.N ? wr : p.N - 1;
+    w_src[j] = (const char*)p.W + ((size_t)wr * p.ldw + lch * 8) * 2;
+  }
+  const unsigned a_dst = lds_base + wid * A_PIECES * 1024;
+  const unsigned w_dst = lds_base + BM * 64 + wid * W_PIECES * 1024;
+
+#define DUO_ISSUE(ST, KT)                                                                   \
+  do {                                                                                      \
+    const int st_ = (ST)*STAGE;                                                             \
+    const int kb_ = (KT)*BK * 2;                                                            \
+    _Pragma("unroll") for (int j = 0; j < A_PIECES; ++j) glds16(a_src[j] + kb_, a_dst + st_ + j * 1024); \
+    _Pragma("unroll") for (int j = 0; j < W_PIECES; ++j) glds16(w_src[j] + kb_, w_dst + st_ + j * 1024); \
+  } while (0)
+
+  f32x4_t acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, g = lane >> 4;
+  const int kc_off = ((g ^ ((-(frow >> 2)) & 3)) << 4);
+  const int x_frag = (wm * WM + frow) * 64 + kc_off;
+  const int w_frag = BM * 64 + (wn * WN + frow) * 64 + kc_off;
+  const int nk = p.K / BK;   // even, >= 2 (K % 64 == 0)
+
+  DUO_ISSUE(0, 0);
+  DUO_ISSUE(1, 1);
+  if (p.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
+    for (int t = 0; t < p.stagger; t += 64) __builtin_amdgcn_s_sleep(64);
+
+  int st = 0;                // stage of slice kt
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // slice kt+1 may stay in flight
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();   // slice kt is in LDS for every wave; all reads of slice kt-1 are done
+    __builtin_amdgcn_sched_barrier(0);
+    const int st2 = st == 0 ? 2 : st - 1;   // (kt + 2) % 3: the stage read during iteration kt-1
+    if (kt + 2 < nk) DUO_ISSUE(st2, kt + 2);
+    const char* cur = smem + st * STAGE;
+    bf16x8_t xf[TM], wf[TN];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) xf[j] = *(const bf16x8_t*)(cur + x_frag + j * 16 * 64);
+#pragma unroll
+    for (int i = 0; i < TN; ++i) wf[i] = *(const bf16x8_t*)(cur + w_frag + i * 16 * 64);
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    st = st == 2 ? 0 : st + 1;
+  }
+#undef DUO_ISSUE
+  __syncthreads();
+  if (p.staged_epi)
+    gemm_epilogue_lds<TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lane, wid, smem);
+  else
+    gemm_epilogue<TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lane);
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 int launch_cfg(const GemmNtArgs& a, hipStream_t stream) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
@@ -689,6 +788,20 @@ int launch_ring(const GemmNtArgs& a, hipStream_t stream) {
   return lc2is_check_launch();
 }
 
+int launch_duo(const GemmNtArgs& a, hipStream_t stream) {
+  constexpr int LDS = 3 * (256 + 128) * 64;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm_nt_duo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
+        hipSuccess)
+      return LC2IS_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int ntm = (a.M + 255) / 256, ntn = (a.N + 127) / 128;
+  hipLaunchKernelGGL(gemm_nt_duo_kernel, dim3(ntm * ntn), dim3(256), LDS, stream, a);
+  return lc2is_check_launch();
+}
+
 int launch_pp(const GemmNtArgs& a, hipStream_t stream) {
   constexpr int LDS = 2 * (256 + 256) * 128;
   static bool attr_set = false;
@@ -724,9 +837,10 @@ extern "C" int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw
   if ((double)(M + 256) * lda * 2.0 >= 2147483648.0 || (double)(N + 256) * ldw * 2.0 >= 2147483648.0)
     return LC2IS_ERR_UNSUPPORTED;
   GemmNtArgs a{(const bf16_t*)A, lda, (const bf16_t*)W, ldw, bias, resid, ldr, (const bf16_t*)aux_in, ldx,
-               (bf16_t*)out_bf16, ldo, out_f32, ldf, (bf16_t*)aux_out, ldy, M, N, K, act, 0};
+               (bf16_t*)out_bf16, ldo, out_f32, ldf, (bf16_t*)aux_out, ldy, M, N, K, act, 0, 0};
   a.staged_epi = (N % 8 == 0) && (!out_bf16 || ldo % 8 == 0) && (!aux_out || ldy % 8 == 0) &&
                  (!aux_in || ldx % 8 == 0) && (out_bf16 || aux_out || aux_in);
+  { static int stg = -1; if (stg < 0) { const char* e = getenv("LC2IS_GEMM_STAGGER"); stg = e ? atoi(e) : 0; } a.stagger = stg; }
   int cfg = tile_cfg;
   if (cfg == 0) {
     const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
@@ -744,6 +858,7 @@ extern "C" int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw
     case 6: return launch_dma<128, 128, 2, 2>(a, stream);
     case 7: return launch_pp(a, stream);
     case 8: return launch_ring(a, stream);
+    case 9: return launch_duo(a, stream);
     // diagnostic ablations of cfg 4 (wrong results by design; tools/gemm_ablate.py only)
     case 41: return launch_dma<256, 256, 2, 4, 1>(a, stream);
     case 42: return launch_dma<256, 256, 2, 4, 2>(a, stream);
