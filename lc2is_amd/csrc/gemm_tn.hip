@@ -12,6 +12,7 @@
 // fp32 slab and a second launch sums the slabs in a fixed order (bitwise reproducible, no atomics).
 #include "common.h"
 #include "lc2is_hip.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -22,10 +23,36 @@ constexpr int TN_STAGE = 2 * TN_TILE_BYTES;
 
 struct TnPlan {
   int ntn, ntk, splits, chunk;
+  int big;  // 1: 256x256 LDS-DMA kernel, 0: 128x128 register-staged kernel
 };
+
+inline int tn_forced_cfg() {  // LC2IS_GEMM_TN_CFG=1|2 pins the kernel choice (tests / tools); default 0 = by shape
+  static int cfg = -1;
+  if (cfg < 0) {
+    const char* e = getenv("LC2IS_GEMM_TN_CFG");
+    cfg = e ? atoi(e) : 0;
+  }
+  return cfg;
+}
 
 inline TnPlan tn_plan(int M, int N, int K) {
   TnPlan p;
+  p.big = 0;
+  if (N % 256 == 0 && K % 256 == 0 && tn_forced_cfg() != 1) {
+    const int ntn = N / 256, ntk = K / 256, tiles = ntn * ntk;
+    int splits = (256 + tiles / 2) / tiles;
+    const int max_splits = (M + 511) / 512;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    if (tiles * splits >= 128 || tn_forced_cfg() == 2) {
+      int chunk = (M + splits - 1) / splits;
+      chunk = (chunk + TN_BM - 1) / TN_BM * TN_BM;
+      p.ntn = ntn; p.ntk = ntk; p.chunk = chunk;
+      p.splits = (M + chunk - 1) / chunk;
+      p.big = 1;
+      return p;
+    }
+  }
   p.ntn = (N + TN_BN - 1) / TN_BN;
   p.ntk = (K + TN_BK - 1) / TN_BK;
   const int tiles = p.ntn * p.ntk;
@@ -203,6 +230,140 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
   }
 }
 
+// ---- 256x256 LDS-DMA variant for the large weight gradients --------------------------------------------------
+// Same scheme on a 256(n) x 256(k) output tile with 8 waves (2 along k x 4 along n, 128x64 each: 24 transposed
+// b64 reads per 32 MFMAs instead of 16 per 16), fed by LDS-DMA: a stage is 64 token rows x (512 B of dY | 512 B of
+// X), a wave instruction moves two rows (1 KiB).  The row swizzle is applied on the GLOBAL side (lane l fetches
+// chunk (l&31) ^ swz(row) of its row), so element (row, chunk) sits at row*512 + ((chunk ^ swz(row)) << 4): the
+// low four chunk bits follow the 128x128 kernel's conflict-free rule, bit 4 is untouched.  Token rows past the
+// split's end are out of the buffer descriptor's range and land in LDS as zeros.
+constexpr int TD_BN = 256, TD_BK = 256;
+constexpr int TD_TILE = TN_BM * 512;    // one operand tile: 64 rows x 512 B
+constexpr int TD_STAGE = 2 * TD_TILE;   // 64 KiB
+
+__device__ __forceinline__ int td_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+__device__ __forceinline__ void td_dma(const bf16_t* dY, unsigned y_bytes, const bf16_t* X, unsigned x_bytes, char* stage,
+                                       int wid, const int* y_goff, const int* x_goff, int ystep, int xstep) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the kernel stub; it has no LDS-DMA builtin
+  const __amdgpu_buffer_rsrc_t rsY = make_rsrc(dY, y_bytes);
+  const __amdgpu_buffer_rsrc_t rsX = make_rsrc(X, x_bytes);
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, LDS_PTR(stage + (wid * 4 + j) * 1024), 16, y_goff[j], ystep, 0, 0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, LDS_PTR(stage + TD_TILE + (wid * 4 + j) * 1024), 16, x_goff[j], xstep,
+                                             0, 0);
+#endif
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_tn_dma_kernel(const bf16_t* __restrict__ dY, int ldy,
+                                                              const bf16_t* __restrict__ X, int ldx, float* out, int ldo,
+                                                              size_t split_stride, float* bias_out,
+                                                              size_t bias_split_stride, int M, int N, int K, int ntn,
+                                                              int ntk, int chunk, int accumulate) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wk = wid >> 2, wn = wid & 3;
+  const int tiles = ntn * ntk;
+  const int split = blockIdx.x / tiles;
+  const int tile = blockIdx.x % tiles;
+  const int n0 = (tile / ntk) * TD_BN, k0 = (tile % ntk) * TD_BK;
+  const int m_begin = split * chunk;
+  int m_end = m_begin + chunk;
+  if (m_end > M) m_end = M;
+  const int nsteps = (m_end - m_begin + TN_BM - 1) / TN_BM;
+  const unsigned y_bytes = (unsigned)m_end * (unsigned)ldy * 2u, x_bytes = (unsigned)m_end * (unsigned)ldx * 2u;
+
+  // DMA: piece 4*wid + j = token rows 2*(4*wid+j), +1; lane -> (row, 16-byte position), source chunk swizzled
+  int y_goff[4], x_goff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = 2 * (wid * 4 + j) + (lane >> 5);
+    const int ch = (lane & 31) ^ td_swz(row);
+    y_goff[j] = ((m_begin + row) * ldy + n0 + ch * 8) * 2;
+    x_goff[j] = ((m_begin + row) * ldx + k0 + ch * 8) * 2;
+  }
+
+  // transposed-read bases: group g owns reduction rows 8g..8g+7 of a 32-row sub-step, lane 4q+p of the group
+  // addresses row 8g+q (lo) / 8g+q+4 (hi), 16-byte chunk 2*t' + (p>>1), byte 8*(p&1).  t' only moves chunk
+  // bits 1..3 = address bits 5..7, so the address of sub-tile t is  base ^ (t << 5).
+  const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+  const int r_lo = 8 * g + q, r_hi = r_lo + 4;
+  const int x_lo = TD_TILE + r_lo * 512 + (((wk * 16 + (pp >> 1)) ^ td_swz(r_lo)) << 4) + 8 * (pp & 1);
+  const int x_hi = TD_TILE + r_hi * 512 + (((wk * 16 + (pp >> 1)) ^ td_swz(r_hi)) << 4) + 8 * (pp & 1);
+  const int y_lo = r_lo * 512 + (((wn * 8 + (pp >> 1)) ^ td_swz(r_lo)) << 4) + 8 * (pp & 1);
+  const int y_hi = r_hi * 512 + (((wn * 8 + (pp >> 1)) ^ td_swz(r_hi)) << 4) + 8 * (pp & 1);
+
+  f32x4_t acc[8][4];  // [k sub-tile][n sub-tile]
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const bool do_cs = (bias_out != nullptr) && (tile % ntk == 0) && (wk == 0);
+  f32x4_t cs[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) cs[b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const s16x8_t ones_s = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_s);
+
+  if (nsteps > 0) td_dma(dY, y_bytes, X, x_bytes, smem, wid, y_goff, x_goff, 0, 0);
+  __syncthreads();  // vmcnt(0) + barrier: stage 0 has landed
+
+  auto mainloop = [&](auto cs_tag) {
+    constexpr bool CS = decltype(cs_tag)::value;
+    for (int st = 0; st < nsteps; ++st) {
+      const char* cur = smem + (st & 1) * TD_STAGE;
+      if (st + 1 < nsteps)
+        td_dma(dY, y_bytes, X, x_bytes, smem + ((st + 1) & 1) * TD_STAGE, wid, y_goff, x_goff,
+               (st + 1) * TN_BM * ldy * 2, (st + 1) * TN_BM * ldx * 2);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8_t xf[8], yf[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) yf[t] = tr_frag(cur + s * 16384, y_lo ^ (t << 5), y_hi ^ (t << 5));
+#pragma unroll
+        for (int t = 0; t < 8; ++t) xf[t] = tr_frag(cur + s * 16384, x_lo ^ (t << 5), x_hi ^ (t << 5));
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int a = 0; a < 8; ++a)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[a], yf[b], acc[a][b], 0, 0, 0);
+        if constexpr (CS) {
+#pragma unroll
+          for (int b = 0; b < 4; ++b) cs[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, yf[b], cs[b], 0, 0, 0);
+        }
+      }
+      __syncthreads();  // reads of `cur` done; the next stage's DMA retired (vmcnt(0)) and published
+    }
+  };
+  if (do_cs) mainloop(std::true_type{}); else mainloop(std::false_type{});
+
+  float* o = out + (size_t)split * split_stride;
+  if (do_cs && lane < 16) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int n = n0 + wn * 64 + b * 16 + lane;
+      float* dst = bias_out + (size_t)split * bias_split_stride + n;
+      *dst = (accumulate ? *dst : 0.f) + cs[b][0];
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int n = n0 + wn * 64 + b * 16 + (lane & 15);
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      const int k = k0 + wk * 128 + a * 16 + g * 4;
+      float* dst = o + (size_t)n * ldo + k;
+      f32x4_t v = acc[a][b];
+      if (accumulate) v += *(const f32x4_t*)dst;
+      *(f32x4_t*)dst = v;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ ws, int splits,
                                                            size_t split_stride, float* out, int ldo, int N,
                                                            int K, int accumulate) {
@@ -296,17 +457,28 @@ extern "C" int lc2is_gemm_tn_bf16(const void* dY, int ldy, const void* X, int ld
       return LC2IS_ERR_LAUNCH;
     attr_set = true;
   }
+  static bool attr_big_set = false;
+  if (p.big && !attr_big_set) {
+    if (hipFuncSetAttribute((const void*)gemm_tn_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            2 * TD_STAGE) != hipSuccess)
+      return LC2IS_ERR_LAUNCH;
+    attr_big_set = true;
+  }
   const int grid = p.ntn * p.ntk * p.splits;
+  auto launch = [&](float* o, int ldo, size_t o_stride, float* b, size_t b_stride, int acc_flag) {
+    if (p.big)
+      hipLaunchKernelGGL(gemm_tn_dma_kernel, dim3(grid), dim3(512), 2 * TD_STAGE, stream, (const bf16_t*)dY, ldy,
+                         (const bf16_t*)X, ldx, o, ldo, o_stride, b, b_stride, M, N, K, p.ntn, p.ntk, p.chunk, acc_flag);
+    else
+      hipLaunchKernelGGL(gemm_tn_kernel, dim3(grid), dim3(256), 2 * TN_STAGE, stream, (const bf16_t*)dY, ldy,
+                         (const bf16_t*)X, ldx, o, ldo, o_stride, b, b_stride, M, N, K, p.ntn, p.ntk, p.chunk, acc_flag);
+  };
   if (p.splits == 1) {
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(grid), dim3(256), 2 * TN_STAGE, stream, (const bf16_t*)dY, ldy,
-                       (const bf16_t*)X, ldx, dW, ldw, (size_t)0, db, (size_t)0, M, N, K, p.ntn, p.ntk, p.chunk,
-                       accumulate);
+    launch(dW, ldw, (size_t)0, db, (size_t)0, accumulate);
     return lc2is_check_launch();
   }
   float* bias_ws = db ? (float*)workspace + (size_t)p.splits * N * K : nullptr;
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3(grid), dim3(256), 2 * TN_STAGE, stream, (const bf16_t*)dY, ldy,
-                     (const bf16_t*)X, ldx, (float*)workspace, K, (size_t)N * K, bias_ws, (size_t)N, M, N, K,
-                     p.ntn, p.ntk, p.chunk, 0);
+  launch((float*)workspace, K, (size_t)N * K, bias_ws, (size_t)N, 0);
   int rc = lc2is_check_launch();
   if (rc) return rc;
   if (db) {
