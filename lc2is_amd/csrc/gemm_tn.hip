@@ -364,12 +364,25 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_dma_kernel(const bf16_t* __res
   }
 }
 
+// blocks [0, gridDim.x - bias_blocks) sum the dW slabs; the last bias_blocks blocks sum the fused bias-gradient
+// partials (one column per thread, fixed order) so the weight gradient needs two launches, not three
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ ws, int splits,
                                                            size_t split_stride, float* out, int ldo, int N,
-                                                           int K, int accumulate) {
+                                                           int K, int accumulate, const float* __restrict__ bias_ws,
+                                                           float* db, int bias_blocks) {
+  const int slab_blocks = gridDim.x - bias_blocks;
+  if ((int)blockIdx.x >= slab_blocks) {
+    const int n = (blockIdx.x - slab_blocks) * 256 + threadIdx.x;
+    if (n < N) {
+      float t = 0.f;
+      for (int sp = 0; sp < splits; ++sp) t += bias_ws[(size_t)sp * N + n];
+      db[n] = accumulate ? db[n] + t : t;
+    }
+    return;
+  }
   const int K4 = K >> 2;
   const size_t total = (size_t)N * K4;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)slab_blocks * 256) {
     const int n = (int)(i / K4), k4 = (int)(i % K4);
     const float4* src = reinterpret_cast<const float4*>(ws + (size_t)n * K) + k4;
     float4 s = *src;
@@ -481,17 +494,12 @@ extern "C" int lc2is_gemm_tn_bf16(const void* dY, int ldy, const void* X, int ld
   launch((float*)workspace, K, (size_t)N * K, bias_ws, (size_t)N, 0);
   int rc = lc2is_check_launch();
   if (rc) return rc;
-  if (db) {
-    hipLaunchKernelGGL(partials_reduce_kernel, dim3((N + 63) / 64, 1), dim3(1024), 0, stream,
-                       (const float*)bias_ws, p.splits, (size_t)N, (size_t)0, N, db, (float*)nullptr, accumulate);
-    rc = lc2is_check_launch();
-    if (rc) return rc;
-  }
   const size_t total4 = (size_t)N * K / 4;
   int rgrid = (int)((total4 + 255) / 256);
   if (rgrid > 2048) rgrid = 2048;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(rgrid), dim3(256), 0, stream, (const float*)workspace, p.splits,
-                     (size_t)N * K, dW, ldw, N, K, accumulate);
+  const int bias_blocks = db ? (N + 255) / 256 : 0;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(rgrid + bias_blocks), dim3(256), 0, stream, (const float*)workspace,
+                     p.splits, (size_t)N * K, dW, ldw, N, K, accumulate, (const float*)bias_ws, db, bias_blocks);
   return lc2is_check_launch();
 }
 

@@ -107,13 +107,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
   const int ldy_ = dyf ? lddyf : lddy;
   for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
     const float mu = mean[row], rs = rstd[row];
-    float4 xh[NV], dy[NV];
+    float4 xh[NV], dy[NV], rv[NV];
     float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {  // the residual-path gradient is fetched with the other operands, not after the reduction
+      const int c4 = lane + 64 * i;
+      rv[i] = (dres && c4 < C4) ? *reinterpret_cast<const float4*>(dres + (size_t)row * lddres + 4 * c4)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c4 = lane + 64 * i;
       if (c4 < C4) {
-        const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)row * ldx + 4 * c4);
+        const f32x4_t xv_ = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(x + (size_t)row * ldx + 4 * c4));
+        const float4 xv = make_float4(xv_[0], xv_[1], xv_[2], xv_[3]);
         dy[i] = load_dy4(dyb, dyf, (size_t)row * ldy_ + 4 * c4);
         xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
         const float a = dy[i].x * gm[i].x, b = dy[i].y * gm[i].y, c = dy[i].z * gm[i].z, d = dy[i].w * gm[i].w;
@@ -134,14 +141,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         o.y = rs * (dy[i].y * gm[i].y - c1 - xh[i].y * c2);
         o.z = rs * (dy[i].z * gm[i].z - c1 - xh[i].z * c2);
         o.w = rs * (dy[i].w * gm[i].w - c1 - xh[i].w * c2);
-        if (dres) {
-          const float4 r = *reinterpret_cast<const float4*>(dres + (size_t)row * lddres + 4 * c4);
-          o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
-        }
-        if (dxf) *reinterpret_cast<float4*>(dxf + (size_t)row * lddx + 4 * c4) = o;
+        o.x += rv[i].x; o.y += rv[i].y; o.z += rv[i].z; o.w += rv[i].w;
+        if (dxf) __builtin_nontemporal_store(f32x4_t{o.x, o.y, o.z, o.w}, reinterpret_cast<f32x4_t*>(dxf + (size_t)row * lddx + 4 * c4));
         if (dxb) {
           uint2 pk = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
-          *reinterpret_cast<uint2*>(dxb + (size_t)row * lddxb + 4 * c4) = pk;
+          __builtin_nontemporal_store(i32x2_t{(int)pk.x, (int)pk.y}, reinterpret_cast<i32x2_t*>(dxb + (size_t)row * lddxb + 4 * c4));
         }
       }
     }
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
 
 inline int ln_bwd_blocks(int M) {
   int nb = (M + 3) / 4;
-  return nb > 512 ? 512 : nb;
+  return nb > 1024 ? 1024 : nb;
 }
 
 }  // namespace
