@@ -8,6 +8,7 @@ from .hier import (CrossABlock, FTNBlock, FTNDecoder, HierarchicalCrossA, Hierar
 from .loss import AuxiliaryLoss, ContrastiveLoss, CrossEntropyLoss, NPairLoss
 from .model import BaseModelWithText, TextToPatch
 from .score import ScoreMapTail
+from . import ftn  # model/ftn.py's Decoder / Transformer keep their (generic) names inside this submodule
 
 __all__ = ["HipModule", "ParamArena", "ClipArch", "ImageEncoderCLIP", "ImageEncoderCLIPFull", "TextEncoderCLIP",
            "TextEncoderCLIPPooler", "DecoderBlock", "DecoderLayer", "PromptDecoder", "PromptLayer", "AuxiliaryLoss", "ContrastiveLoss", "CrossEntropyLoss", "NPairLoss",

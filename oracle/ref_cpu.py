@@ -459,6 +459,55 @@ def hierarchical(sd: dict, pre: str, visual: list, textual: Tensor | None, nhead
     return t1 + t2 + t3 + t4
 
 
+# ----------------------------------------------------------------------------------------------------------
+# the older FTN pyramid: model/ftn.py:67-157
+# ----------------------------------------------------------------------------------------------------------
+def std_decoder_layer(sd: dict, pre: str, tgt: Tensor, memory: Tensor, nhead: int, eps: float = 1e-5) -> Tensor:
+    """nn.TransformerDecoderLayer(d, nhead, batch_first=True) forward, post-norm, relu, dropout off
+    (torch:nn/modules/transformer.py:1147-1156), as instantiated at model/ftn.py:135."""
+    g = lambda k: sd.get(pre + k)  # noqa: E731
+    x = tgt
+    x = layer_norm(x + _mha_packed(sd, pre + "self_attn.", x, x, nhead), g("norm1.weight"), g("norm1.bias"), eps)
+    x = layer_norm(x + _mha_packed(sd, pre + "multihead_attn.", x, memory, nhead), g("norm2.weight"), g("norm2.bias"), eps)
+    ff = linear(torch.relu(linear(x, g("linear1.weight"), g("linear1.bias"))), g("linear2.weight"), g("linear2.bias"))
+    return layer_norm(x + ff, g("norm3.weight"), g("norm3.bias"), eps)
+
+
+def _up2_grid(x: Tensor, h: int) -> Tensor:
+    """tokens as an h x (P/h) grid -> bilinear x2 -> tokens (model/ftn.py:153-155; h is NOT updated between layers)."""
+    B, P, C = x.shape
+    y = upsample2d(x.reshape(B, h, P // h, C).permute(0, 3, 1, 2), scale_factor=2, mode="bilinear")
+    return y.permute(0, 2, 3, 1).reshape(B, 4 * P, C)
+
+
+def ftn_transformer(sd: dict, pre: str, x: Tensor, h: int, repeat: int, sr_ratio: int, upsample: bool,
+                    nhead: int) -> Tensor:
+    """ftn.Transformer.forward (model/ftn.py:143-157): memory = LayerNorm(Conv2d(k=sr, s=sr)(x grid)) of the block
+    input (x itself when sr_ratio == 1); `repeat` decoder layers, each followed by the x2 upsample when enabled."""
+    memory = sr_reduce(sd, pre, x) if sr_ratio > 1 else x
+    for r in range(repeat):
+        x = std_decoder_layer(sd, f"{pre}trans.{r}.layers.0.", x, memory, nhead)
+        if upsample:
+            x = _up2_grid(x, h)
+    return x
+
+
+def ftn_decoder(sd: dict, pre: str, xs: list) -> Tensor:
+    """ftn.Decoder.forward (model/ftn.py:103-129): grids [128,64,32,16]; stages 1 and 2 add the bilinear x2 of the
+    NEXT stage's raw input; attentions[0] is never applied."""
+    H = [128, 64, 32, 16]
+    L = lambda name, x: linear(x, sd[pre + name + ".weight"], sd[pre + name + ".bias"])  # noqa: E731
+    out = [L(f"linears.{i}", xs[i]) for i in range(4)]
+    for i in (1, 2):
+        out[i] = out[i] + _up2_grid(xs[i + 1], H[i + 1])
+    cfg = {1: (1, 8), 2: (2, 8), 3: (3, 8)}   # stage -> (repeat, nhead), model/ftn.py:84-89
+    end = L("linears2.0", out[0])
+    for i in range(1, 4):
+        rep, nh = cfg[i]
+        end = end + ftn_transformer(sd, f"{pre}attentions.{i}.", L(f"linears2.{i}", out[i]), H[i], rep, 2, True, nh)
+    return end
+
+
 def score_map_tail(visual_embeddings: Tensor, text_embeddings: Tensor, scale: int = 4) -> Tensor:
     """model/final.py:350-356 (same ops at model/model.py:204-212, model/ftn.py:56-62): tokens -> NCHW, L2-normalise
     both sides over channels, einsum('bchw,bkc->bkhw'), bilinear x4."""

@@ -269,16 +269,52 @@ def make_hier(R):
     print("hier:", {k: (tuple(v["out"].shape) if isinstance(v, dict) and "out" in v else None) for k, v in fx.items()})
 
 
+def make_ftn(R):
+    """ftn.Decoder (model/ftn.py:67-129) at its hard-coded dims (Swin-base widths, grids 128/64/32/16), B=1, eval mode
+    (the reference hard-codes torch's default dropout 0.1), forward + backward.  Inputs, weights and the output
+    gradient are regenerated from seeds by the tests; the fixture keeps every 61st row of the big tensors."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    from golden_util import ftn_inputs, make_weights
+    import model.ftn as rftn
+    m = rftn.Decoder().eval()
+    params = dict(m.named_parameters())
+    shapes = {k: list(v.shape) for k, v in params.items()}
+    w = make_weights(shapes, 51)
+    with torch.no_grad():
+        for k, p in params.items():
+            p.copy_(w[k])
+    xs, dout = ftn_inputs(52)
+    xs = [x.requires_grad_(True) for x in xs]
+    out = m(xs)
+    out.backward(dout)
+    st = 61
+    fx = dict(shapes={k: torch.tensor(v) for k, v in shapes.items()}, wseed=torch.tensor(51), xseed=torch.tensor(52),
+              stride=torch.tensor(st), out=out.detach()[:, ::st].clone(),
+              dx=[x.grad[:, ::st].clone() for x in xs],
+              grad_stats={k: (torch.stack([p.grad.sum(), p.grad.abs().sum()]) if p.grad is not None else torch.zeros(2))
+                          for k, p in params.items()},
+              no_grad=[k for k, p in params.items() if p.grad is None],
+              grad_full={k: params[k].grad.clone() for k in params
+                         if params[k].grad is not None and params[k].numel() <= 1024 and ("norm" in k or k.endswith("bias"))})
+    fx["no_grad"] = torch.tensor([list(params).index(k) for k in fx["no_grad"]])
+    torch.save(fx, OUT / "ftn_decoder.pt")
+    print("ftn:", tuple(out.shape), "params without grad:", len(fx["no_grad"]), "fixture rows:", fx["out"].shape[1])
+
+
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
     R = _ref_imports()
     if len(sys.argv) > 1 and sys.argv[1] == "hier":
         make_hier(R)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "ftn":
+        make_ftn(R)
+        return
     make_base_tiny(R)
     make_decoder_d96(R)
     make_ops(R)
     make_hier(R)
+    make_ftn(R)
     # the reference's only data fixture on this path (SURVEY.md §2 row 8) — copied as-is
     protos = torch.load(REF / "model" / "ade20k_prototypes.pt", weights_only=True)
     torch.save(protos.clone(), OUT / "ade20k_prototypes.pt")
