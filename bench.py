@@ -103,6 +103,16 @@ def cpu_baseline(arch_kwargs, in_size, out_size, L, sample_images, steps):
                 sample=f"{steps} train steps of batch {sample_images} at {in_size}x{in_size} (fp32 oracle, 1 warm-up)")
 
 
+def pmc_traffic(args):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_v4_pmc_hbm.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this same command, gfx950 corrections applied).  Counters cannot be
+    read from inside the timed process, so the figure is the recorded one and only for the workload it was taken on."""
+    f = Path(__file__).resolve().parent / "profiles" / "r01_v4_pmc_hbm.json"
+    if args.patch != 16 or args.batch != 32 or args.in_size != 512 or not f.exists():
+        return None
+    return json.loads(f.read_text())["hbm_bytes_per_launch"]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -210,7 +220,7 @@ def main():
             "final_loss": loss_val,
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel (all bf16 NT GEMM launches of the timed steps)",
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(args),
                          "launches_per_step": gsum["launches"] / timed_steps, "hip_graph": use_graph,
                          "avg_launch_us": gsum["seconds"] / max(gsum["launches"], 1) * 1e6,
                          "gemm_nt_time_share": gsum["seconds"] / timed_steps / (dt / args.steps)},
