@@ -28,6 +28,9 @@ extern "C" {
 #define LC2IS_ACT_RELU 2        /* F.relu default of model/decoder.py:11                                */
 #define LC2IS_ACT_DQUICK_GELU 3 /* backward: acc * quick_gelu'(aux_in)                                  */
 #define LC2IS_ACT_DRELU 4       /* backward: acc * (aux_in > 0)                                          */
+#define LC2IS_ACT_QUICK_GELU_GRAD 5 /* forward: out = quick_gelu(z), aux_out = quick_gelu'(z) (bf16) — saves the
+                                      backward's transcendentals; pair with LC2IS_ACT_MUL_AUX            */
+#define LC2IS_ACT_MUL_AUX 6     /* backward: acc * aux_in (aux_in = the derivative saved by code 5)     */
 
 #define LC2IS_INTERP_BICUBIC 0  /* F.interpolate(mode="bicubic", align_corners=False), A = -0.75, border clamp */
 #define LC2IS_INTERP_BILINEAR 1 /* F.interpolate(mode="bilinear", align_corners=False)                          */

@@ -33,7 +33,6 @@ struct GemmNtArgs {
   bf16_t* aux_out; int ldy;
   int M, N, K, act;
   int staged_epi;  // bf16 epilogue traffic through LDS (needs N % 8 == 0 and 8-element-aligned leading dims)
-  int stagger;     // experiment: start-up delay (units of 64 clocks) of the second co-resident block
 };
 
 __device__ __forceinline__ float sigmoidf_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }  // v_exp + v_rcp
@@ -55,7 +54,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmNtArgs& p, f32x4_t (&acc
       const int m = m0 + wm * WM + j * 16 + frow;
       if (m >= p.M) continue;
       f32x4_t v = acc[i][j] + bv;
-      if (act == LC2IS_ACT_QUICK_GELU || act == LC2IS_ACT_RELU) {
+      if (act == LC2IS_ACT_QUICK_GELU_GRAD) {
+        f32x4_t d;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float sg = sigmoidf_fast(1.702f * v[r]);
+          d[r] = sg * (1.f + 1.702f * v[r] * (1.f - sg));
+          v[r] *= sg;
+        }
+        if (p.aux_out) {
+          i32x2_t pk = {(int)pack_bf16x2(d[0], d[1]), (int)pack_bf16x2(d[2], d[3])};
+          *(i32x2_t*)(p.aux_out + (size_t)m * p.ldy + n) = pk;
+        }
+      } else if (act == LC2IS_ACT_QUICK_GELU || act == LC2IS_ACT_RELU) {
         if (p.aux_out) {
           i32x2_t pk = {(int)pack_bf16x2(v[0], v[1]), (int)pack_bf16x2(v[2], v[3])};
           *(i32x2_t*)(p.aux_out + (size_t)m * p.ldy + n) = pk;
@@ -63,13 +74,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmNtArgs& p, f32x4_t (&acc
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           v[r] = (act == LC2IS_ACT_RELU) ? fmaxf(v[r], 0.f) : v[r] * sigmoidf_fast(1.702f * v[r]);
-      } else if (act == LC2IS_ACT_DQUICK_GELU || act == LC2IS_ACT_DRELU) {
+      } else if (act == LC2IS_ACT_DQUICK_GELU || act == LC2IS_ACT_DRELU || act == LC2IS_ACT_MUL_AUX) {
         const i32x2_t zk = *(const i32x2_t*)(p.aux_in + (size_t)m * p.ldx + n);
         float z[4] = {bf16_to_f32((bf16_t)(zk[0] & 0xffff)), bf16_to_f32((bf16_t)((unsigned)zk[0] >> 16)),
                       bf16_to_f32((bf16_t)(zk[1] & 0xffff)), bf16_to_f32((bf16_t)((unsigned)zk[1] >> 16))};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          if (act == LC2IS_ACT_DRELU) {
+          if (act == LC2IS_ACT_MUL_AUX) {
+            v[r] *= z[r];
+          } else if (act == LC2IS_ACT_DRELU) {
             v[r] = z[r] > 0.f ? v[r] : 0.f;
           } else {
             const float s = sigmoidf_fast(1.702f * z[r]);
@@ -104,19 +117,27 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmNtArgs& p, f32x4_t (
   const int nw = n0 + wn * WN;
   const bool col_ok = (nw + sch * 8) < p.N;
 
+  // ---- (A) saved pre-activation / derivative for the backward epilogues: all of the wave's rows are requested up
+  // front (one latency for the tile instead of one per 64-row group), then land in the patch group by group ----
+  const bool has_aux = act == LC2IS_ACT_DQUICK_GELU || act == LC2IS_ACT_DRELU || act == LC2IS_ACT_MUL_AUX;
+  i32x4_t auxv[TM / 4][8];
+  if (has_aux) {
+#pragma unroll
+    for (int jg = 0; jg < TM / 4; ++jg)
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int m = m0 + wm * WM + jg * 64 + it * 8 + srow;
+        auxv[jg][it] = i32x4_t{0, 0, 0, 0};
+        if (m < p.M && col_ok) auxv[jg][it] = *(const i32x4_t*)(p.aux_in + (size_t)m * p.ldx + nw + sch * 8);
+      }
+  }
 #pragma unroll
   for (int jg = 0; jg < TM / 4; ++jg) {
     const int mrow0 = m0 + wm * WM + jg * 64;
     if (mrow0 >= p.M) break;  // wave-uniform
-    // ---- (A) saved pre-activation for the derivative epilogues: HBM -> patch (coalesced) ----
-    if (act == LC2IS_ACT_DQUICK_GELU || act == LC2IS_ACT_DRELU) {
+    if (has_aux) {
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int r = it * 8 + srow, m = mrow0 + r;
-        i32x4_t v = {0, 0, 0, 0};
-        if (m < p.M && col_ok) v = *(const i32x4_t*)(p.aux_in + (size_t)m * p.ldx + nw + sch * 8);
-        *(i32x4_t*)(patch + r * PITCH + sch * 16) = v;
-      }
+      for (int it = 0; it < 8; ++it) *(i32x4_t*)(patch + (it * 8 + srow) * PITCH + sch * 16) = auxv[jg][it];
     }
     // ---- (B) bias, derivative / pre-activation ----
 #pragma unroll
@@ -127,13 +148,25 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmNtArgs& p, f32x4_t (
 #pragma unroll
       for (int jl = 0; jl < 4; ++jl) {
         f32x4_t v = acc[i][jg * 4 + jl] + bv;
-        if (act == LC2IS_ACT_DQUICK_GELU || act == LC2IS_ACT_DRELU) {
+        if (act == LC2IS_ACT_QUICK_GELU_GRAD) {   // activation now, its derivative (bf16) into the patch for (C)
+          f32x4_t d;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float sg = sigmoidf_fast(1.702f * v[r]);
+            d[r] = sg * (1.f + 1.702f * v[r] * (1.f - sg));
+            v[r] *= sg;
+          }
+          i32x2_t pk = {(int)pack_bf16x2(d[0], d[1]), (int)pack_bf16x2(d[2], d[3])};
+          *(i32x2_t*)(patch + (jl * 16 + frow) * PITCH + (i * 16 + g * 4) * 2) = pk;
+        } else if (act == LC2IS_ACT_DQUICK_GELU || act == LC2IS_ACT_DRELU || act == LC2IS_ACT_MUL_AUX) {
           const i32x2_t zk = *(const i32x2_t*)(patch + (jl * 16 + frow) * PITCH + (i * 16 + g * 4) * 2);
           float z[4] = {bf16_to_f32((bf16_t)(zk[0] & 0xffff)), bf16_to_f32((bf16_t)((unsigned)zk[0] >> 16)),
                         bf16_to_f32((bf16_t)(zk[1] & 0xffff)), bf16_to_f32((bf16_t)((unsigned)zk[1] >> 16))};
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            if (act == LC2IS_ACT_DRELU) {
+            if (act == LC2IS_ACT_MUL_AUX) {
+              v[r] *= z[r];
+            } else if (act == LC2IS_ACT_DRELU) {
               v[r] = z[r] > 0.f ? v[r] : 0.f;
             } else {
               const float sg = sigmoidf_fast(1.702f * z[r]);
@@ -144,16 +177,18 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmNtArgs& p, f32x4_t (
         acc[i][jg * 4 + jl] = v;
       }
     }
-    // ---- (C) store the pre-activation (bf16) ----
-    if ((act == LC2IS_ACT_QUICK_GELU || act == LC2IS_ACT_RELU) && p.aux_out) {
+    // ---- (C) store the pre-activation (bf16), or the derivative (B) left in the patch ----
+    if ((act == LC2IS_ACT_QUICK_GELU || act == LC2IS_ACT_RELU || act == LC2IS_ACT_QUICK_GELU_GRAD) && p.aux_out) {
+      if (act != LC2IS_ACT_QUICK_GELU_GRAD) {
 #pragma unroll
-      for (int i = 0; i < TN; ++i)
+        for (int i = 0; i < TN; ++i)
 #pragma unroll
-        for (int jl = 0; jl < 4; ++jl) {
-          const f32x4_t v = acc[i][jg * 4 + jl];
-          i32x2_t pk = {(int)pack_bf16x2(v[0], v[1]), (int)pack_bf16x2(v[2], v[3])};
-          *(i32x2_t*)(patch + (jl * 16 + frow) * PITCH + (i * 16 + g * 4) * 2) = pk;
-        }
+          for (int jl = 0; jl < 4; ++jl) {
+            const f32x4_t v = acc[i][jg * 4 + jl];
+            i32x2_t pk = {(int)pack_bf16x2(v[0], v[1]), (int)pack_bf16x2(v[2], v[3])};
+            *(i32x2_t*)(patch + (jl * 16 + frow) * PITCH + (i * 16 + g * 4) * 2) = pk;
+          }
+      }
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int r = it * 8 + srow, m = mrow0 + r;
@@ -654,7 +689,7 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(GemmNtArgs p) {
 // after the barrier of slice t and waited with a counted vmcnt (one younger slice stays in flight).  Accumulation
 // order per output element equals the other kernels' (bitwise-equal results).
 __global__ __launch_bounds__(256, 2) void gemm_nt_duo_kernel(GemmNtArgs p) {
-  constexpr int BM = 256, BN = 128, WAVES_N = 2, BK = 32, NST = 3;
+  constexpr int BM = 256, BN = 128, WAVES_N = 2, BK = 32;   // 3-deep stage ring
   constexpr int WM = 128, WN = 64, TM = 8, TN = 4;
   constexpr int A_PIECES = 4, W_PIECES = 2;   // 1-KiB pieces (16 rows x 64 B) per wave per stage
   constexpr int STAGE = (BM + BN) * 64;       // 24 KiB
@@ -709,8 +744,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_duo_kernel(GemmNtArgs p) {
 
   DUO_ISSUE(0, 0);
   DUO_ISSUE(1, 1);
-  if (p.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
-    for (int t = 0; t < p.stagger; t += 64) __builtin_amdgcn_s_sleep(64);
 
   int st = 0;                // stage of slice kt
   for (int kt = 0; kt < nk; ++kt) {
@@ -831,16 +864,15 @@ extern "C" int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw
   if ((out_bf16 && (ldo < N || ldo % 4)) || (out_f32 && (ldf < N || ldf % 4)) || (resid && (ldr < N || ldr % 4)) ||
       (aux_in && (ldx < N || ldx % 4)) || (aux_out && (ldy < N || ldy % 4)))
     return LC2IS_ERR_SHAPE;
-  if ((act == LC2IS_ACT_DQUICK_GELU || act == LC2IS_ACT_DRELU) && !aux_in) return LC2IS_ERR_NULL;
-  if (act < LC2IS_ACT_NONE || act > LC2IS_ACT_DRELU) return LC2IS_ERR_UNSUPPORTED;
+  if ((act == LC2IS_ACT_DQUICK_GELU || act == LC2IS_ACT_DRELU || act == LC2IS_ACT_MUL_AUX) && !aux_in) return LC2IS_ERR_NULL;
+  if (act < LC2IS_ACT_NONE || act > LC2IS_ACT_MUL_AUX) return LC2IS_ERR_UNSUPPORTED;
   // 32-bit buffer offsets: operand panels (plus one tile of overhang) must stay under 2 GiB
   if ((double)(M + 256) * lda * 2.0 >= 2147483648.0 || (double)(N + 256) * ldw * 2.0 >= 2147483648.0)
     return LC2IS_ERR_UNSUPPORTED;
   GemmNtArgs a{(const bf16_t*)A, lda, (const bf16_t*)W, ldw, bias, resid, ldr, (const bf16_t*)aux_in, ldx,
-               (bf16_t*)out_bf16, ldo, out_f32, ldf, (bf16_t*)aux_out, ldy, M, N, K, act, 0, 0};
+               (bf16_t*)out_bf16, ldo, out_f32, ldf, (bf16_t*)aux_out, ldy, M, N, K, act, 0};
   a.staged_epi = (N % 8 == 0) && (!out_bf16 || ldo % 8 == 0) && (!aux_out || ldy % 8 == 0) &&
                  (!aux_in || ldx % 8 == 0) && (out_bf16 || aux_out || aux_in);
-  { static int stg = -1; if (stg < 0) { const char* e = getenv("LC2IS_GEMM_STAGGER"); stg = e ? atoi(e) : 0; } a.stagger = stg; }
   int cfg = tile_cfg;
   if (cfg == 0) {
     const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);

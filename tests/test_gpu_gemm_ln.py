@@ -75,6 +75,31 @@ def test_gemm_nt_activation_and_backward_epilogue(dev, act, cfg):
     assert _rel(dz.float(), ref) < 5e-3
 
 
+@pytest.mark.parametrize("cfg", [0, 3, 4, 9])
+def test_gemm_nt_gelu_derivative_pair(dev, cfg):
+    """Codes 5/6: the forward epilogue saves quick_gelu'(z) (bf16) next to the activation; the backward epilogue
+    multiplies by it.  cfg 3 = direct epilogue, 4/9 = LDS-staged epilogue."""
+    from lc2is_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(6)
+    M, N, K = 515, 384, 192
+    a = _bf(torch.randn(M, K, generator=g)).to(dev)
+    w = _bf(torch.randn(N, K, generator=g) * 0.1).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    ob, _, d = ops.gemm_nt(a, w, bias, act=ops.ACT_QUICK_GELU_GRAD, aux_out=True, tile_cfg=cfg)
+    zr = a.double() @ w.double().T + bias.double()
+    sg = torch.sigmoid(1.702 * zr)
+    assert _rel(ob.float(), zr * sg) < 4e-3
+    dref = sg * (1 + 1.702 * zr * (1 - sg))
+    assert _rel(d.float(), dref) < 4e-3
+    ob2, _, _ = ops.gemm_nt(a, w, bias, act=ops.ACT_QUICK_GELU, tile_cfg=cfg)       # same activation as code 1
+    assert _rel(ob.float(), ob2.float().double()) < 1e-6
+    dy = _bf(torch.randn(M, K, generator=g)).to(dev)
+    dz, _, _ = ops.gemm_nt(dy, w, None, act=ops.ACT_MUL_AUX, aux_in=d, tile_cfg=cfg)
+    assert _rel(dz.float(), (dy.double() @ w.double().T) * d.double()) < 4e-3
+    with pytest.raises(RuntimeError):
+        ops.gemm_nt(dy, w, None, act=ops.ACT_MUL_AUX, tile_cfg=cfg)                    # aux_in is required
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 128, 128), (1025, 768, 768), (4100, 2304, 768), (2050, 152, 512),
                                    (64, 64, 64), (5000, 3072, 768), (33, 8, 8)])
 def test_gemm_tn(dev, M, N, K):
