@@ -160,6 +160,8 @@ def main():
     in_size, out_size = args.in_size, 4 * (args.in_size // args.patch)
     torch.manual_seed(1024)  # evaluate.py:24 default seed; identical replica on every rank
     model = N.BaseModelWithText(patch_size=args.patch, in_size=in_size, out_size=out_size).to(dev).train()
+    if os.environ.get("LC2IS_SERIAL_TEXT"):   # A/B switch: keep the text tower on the main stream
+        model.overlap_text = False
     if world > 1:
         reducer = GradReducer()
     ts = TrainStep(model, optimizer=args.optimizer, lr=1e-5, reducer=reducer)  # all_args.sh:15 LR

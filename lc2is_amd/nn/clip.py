@@ -384,6 +384,14 @@ class _TextFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
+        # autograd replays this node on the stream its forward ran on.  When that is a side stream (the composition
+        # overlaps the text tower with the vision tower) the incoming gradient was produced on another stream, and
+        # the parameter gradients below are written by kernels autograd knows nothing about: keep the allocator from
+        # recycling `gout` early and make the stream that called backward() wait for this one before it returns.
+        here = torch.cuda.current_stream(gout.device)
+        gout.record_stream(here)
+        torch.autograd.Variable._execution_engine.queue_callback(
+            lambda: torch.cuda.current_stream(gout.device).wait_stream(here))
         ctx.mod._bwd(gout.contiguous(), ctx.saved)
         ctx.saved = None
         return None, None, None, None, None

@@ -121,6 +121,8 @@ class BaseModelWithText(HipModule):
         self.pixel_patch = TextToPatch(out=out_dim, img_in=cv, text_in=self.class_prototypes.shape[1])
         if self.class_prototypes.shape[0] > KPAD:
             raise ValueError(f"BaseModelWithText: at most {KPAD} classes are supported by the fused head")
+        self.overlap_text = True     # text tower on a side stream (set False to serialise, e.g. under graph capture)
+        self._text_stream = None
 
     # -- shadows owned by the composition: padded bf16 prototypes -------------------------------------------
     def _params_for_version(self):
@@ -196,8 +198,26 @@ class BaseModelWithText(HipModule):
     def _decode(self, inputs):
         vision_inputs = {k: v for k, v in inputs.items() if k in ["pixel_values"]}
         text_inputs = {k: v for k, v in inputs.items() if k in ["input_ids", "attention_mask"]}
-        enc_t = self.text_encoder(**text_inputs)                                              # model.py:32
-        enc_v = self.vision_encoder(**vision_inputs)                                          # model.py:35
+        if self.overlap_text and text_inputs["input_ids"].is_cuda:
+            # The text tower is ~400 tiny launches (B*L = 512 tokens at config 2) that leave most of the 256 CUs idle:
+            # it runs on a side HIP stream under the vision tower's large kernels (autograd replays its backward on
+            # the same stream, again beside the vision backward).
+            dev = text_inputs["input_ids"].device
+            main = torch.cuda.current_stream(dev)
+            if self._text_stream is None or self._text_stream.device != dev:
+                self._text_stream = torch.cuda.Stream(dev)
+            side = self._text_stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                for t in text_inputs.values():
+                    t.record_stream(side)
+                enc_t = self.text_encoder(**text_inputs)                                      # model.py:32
+            enc_v = self.vision_encoder(**vision_inputs)                                      # model.py:35
+            main.wait_stream(side)
+            enc_t.record_stream(main)
+        else:
+            enc_t = self.text_encoder(**text_inputs)                                          # model.py:32
+            enc_v = self.vision_encoder(**vision_inputs)                                      # model.py:35
         kpm = torch.where(text_inputs["attention_mask"] == 1, False, True)                    # model.py:38
         return self.vision_decoder(tgt=enc_v, memory=enc_t, memory_key_padding_mask=kpm)
 

@@ -75,6 +75,8 @@ class TrainStep:
         Single-process only (the RCCL reduction is not captured)."""
         if self.reducer is not None:
             raise RuntimeError("TrainStep.capture: graph capture is only wired for single-GPU steps")
+        if hasattr(self.model, "overlap_text"):
+            self.model.overlap_text = False   # one captured stream: the side-stream fork is an eager-mode optimisation
         static_in = {k: v.clone() for k, v in inputs.items()}
         static_lb = labels.clone()
         side = torch.cuda.Stream()
