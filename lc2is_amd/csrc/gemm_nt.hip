@@ -37,20 +37,41 @@ struct GemmNtArgs {
 
 __device__ __forceinline__ float sigmoidf_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }  // v_exp + v_rcp
 
-template <int TM, int TN, int WM, int WN>
-__device__ __forceinline__ void gemm_epilogue(const GemmNtArgs& p, f32x4_t (&acc)[TN][TM], int m0, int n0, int wm,
-                                              int wn, int lane) {
+// The activation code is a template parameter of both epilogues: with a run-time `act` inside the unrolled sub-tile
+// loops the kernels carried every variant inline (25k instructions for the 256x256 kernel, more than the instruction
+// cache), and each tile's epilogue was paced by instruction fetch.  One compact straight-line variant runs per launch.
+template <int act, int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void gemm_epilogue_act(const GemmNtArgs& p, f32x4_t (&acc)[TN][TM], int m0, int n0, int wm,
+                                                  int wn, int lane) {
   const int frow = lane & 15, g = lane >> 4;
   // ---- epilogue: lane holds C[m][n..n+3], n = 4*(lane>>4) within the 16-wide sub-tile ----
-  const int act = p.act;
 #pragma unroll
   for (int i = 0; i < TN; ++i) {
     const int n = n0 + wn * WN + i * 16 + g * 4;
     if (n >= p.N) continue;
     f32x4_t bv = f32x4_t{0.f, 0.f, 0.f, 0.f};
     if (p.bias) bv = *(const f32x4_t*)(p.bias + n);
+    // every load of this column of sub-tiles is issued before its first store: the outputs may alias the inputs
+    // (in-place residual), so the compiler will not hoist them itself and each sub-tile would pay a full load latency
+    constexpr bool kAux = act == LC2IS_ACT_DQUICK_GELU || act == LC2IS_ACT_DRELU || act == LC2IS_ACT_MUL_AUX;
+    constexpr int PF = TM < 4 ? TM : 4;   // sub-tiles prefetched together (more would spill beside 128 accumulators)
 #pragma unroll
-    for (int j = 0; j < TM; ++j) {
+    for (int j0 = 0; j0 < TM; j0 += PF) {
+    f32x4_t rv[PF];
+    i32x2_t zv[PF];
+#pragma unroll
+    for (int jj = 0; jj < PF; ++jj) {
+      const int m = m0 + wm * WM + (j0 + jj) * 16 + frow;
+      rv[jj] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      zv[jj] = i32x2_t{0, 0};
+      if (m < p.M) {
+        if (p.resid) rv[jj] = *(const f32x4_t*)(p.resid + (size_t)m * p.ldr + n);
+        if (kAux) zv[jj] = *(const i32x2_t*)(p.aux_in + (size_t)m * p.ldx + n);
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj < PF; ++jj) {
+      const int j = j0 + jj;
       const int m = m0 + wm * WM + j * 16 + frow;
       if (m >= p.M) continue;
       f32x4_t v = acc[i][j] + bv;
@@ -74,8 +95,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmNtArgs& p, f32x4_t (&acc
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           v[r] = (act == LC2IS_ACT_RELU) ? fmaxf(v[r], 0.f) : v[r] * sigmoidf_fast(1.702f * v[r]);
-      } else if (act == LC2IS_ACT_DQUICK_GELU || act == LC2IS_ACT_DRELU || act == LC2IS_ACT_MUL_AUX) {
-        const i32x2_t zk = *(const i32x2_t*)(p.aux_in + (size_t)m * p.ldx + n);
+      } else if (kAux) {
+        const i32x2_t zk = zv[jj];
         float z[4] = {bf16_to_f32((bf16_t)(zk[0] & 0xffff)), bf16_to_f32((bf16_t)((unsigned)zk[0] >> 16)),
                       bf16_to_f32((bf16_t)(zk[1] & 0xffff)), bf16_to_f32((bf16_t)((unsigned)zk[1] >> 16))};
 #pragma unroll
@@ -90,14 +111,34 @@ __device__ __forceinline__ void gemm_epilogue(const GemmNtArgs& p, f32x4_t (&acc
           }
         }
       }
-      if (p.resid) v += *(const f32x4_t*)(p.resid + (size_t)m * p.ldr + n);
+      v += rv[jj];
       if (p.out_f32) *(f32x4_t*)(p.out_f32 + (size_t)m * p.ldf + n) = v;
       if (p.out_bf16) {
         i32x2_t pk = {(int)pack_bf16x2(v[0], v[1]), (int)pack_bf16x2(v[2], v[3])};
         *(i32x2_t*)(p.out_bf16 + (size_t)m * p.ldo + n) = pk;
       }
     }
+    }
   }
+}
+
+#define LC2IS_ACT_SWITCH(CALL)                          \
+  switch (p.act) {                                      \
+    case LC2IS_ACT_QUICK_GELU: CALL(LC2IS_ACT_QUICK_GELU); break;             \
+    case LC2IS_ACT_RELU: CALL(LC2IS_ACT_RELU); break;                         \
+    case LC2IS_ACT_DQUICK_GELU: CALL(LC2IS_ACT_DQUICK_GELU); break;           \
+    case LC2IS_ACT_DRELU: CALL(LC2IS_ACT_DRELU); break;                       \
+    case LC2IS_ACT_QUICK_GELU_GRAD: CALL(LC2IS_ACT_QUICK_GELU_GRAD); break;   \
+    case LC2IS_ACT_MUL_AUX: CALL(LC2IS_ACT_MUL_AUX); break;                   \
+    default: CALL(LC2IS_ACT_NONE); break;                                     \
+  }
+
+template <int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void gemm_epilogue(const GemmNtArgs& p, f32x4_t (&acc)[TN][TM], int m0, int n0, int wm,
+                                              int wn, int lane) {
+#define LC2IS_EPI_CALL(A) gemm_epilogue_act<A, TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lane)
+  LC2IS_ACT_SWITCH(LC2IS_EPI_CALL)
+#undef LC2IS_EPI_CALL
 }
 
 // LDS-staged epilogue for the LDS-DMA kernels (WN == 64): every bf16 tensor touched by the epilogue (saved
@@ -105,46 +146,46 @@ __device__ __forceinline__ void gemm_epilogue(const GemmNtArgs& p, f32x4_t (&acc
 // lane, 8 rows per wave instruction) through a private per-wave LDS patch, instead of 8-byte pieces whose
 // 32-byte row fragments cost partial-line writes.  fp32 residual / output keep the direct 16-B (64 B per row)
 // form.  Only in-order LDS traffic of one wave touches a patch, so no barrier is needed.
-template <int TM, int TN, int WM, int WN>
-__device__ __forceinline__ void gemm_epilogue_lds(const GemmNtArgs& p, f32x4_t (&acc)[TN][TM], int m0, int n0, int wm,
-                                                  int wn, int lane, int wid, char* smem) {
+template <int act, int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void gemm_epilogue_lds_act(const GemmNtArgs& p, f32x4_t (&acc)[TN][TM], int m0, int n0,
+                                                      int wm, int wn, int lane, int wid, char* smem) {
   static_assert(WN == 64 && TM % 4 == 0, "staged epilogue expects 64-column wave tiles");
   constexpr int PITCH = 144;                 // 128 B of data + 16: conflict-free ds_write_b64 / ds_read_b128
   char* patch = smem + wid * (64 * PITCH);
   const int frow = lane & 15, g = lane >> 4;
   const int srow = lane >> 3, sch = lane & 7;  // flush mapping: 8 rows x 8 chunks per wave instruction
-  const int act = p.act;
   const int nw = n0 + wn * WN;
   const bool col_ok = (nw + sch * 8) < p.N;
 
-  // ---- (A) saved pre-activation / derivative for the backward epilogues: all of the wave's rows are requested up
-  // front (one latency for the tile instead of one per 64-row group), then land in the patch group by group ----
-  const bool has_aux = act == LC2IS_ACT_DQUICK_GELU || act == LC2IS_ACT_DRELU || act == LC2IS_ACT_MUL_AUX;
-  i32x4_t auxv[TM / 4][8];
-  if (has_aux) {
+  constexpr bool has_aux = act == LC2IS_ACT_DQUICK_GELU || act == LC2IS_ACT_DRELU || act == LC2IS_ACT_MUL_AUX;
+  f32x4_t bvs[TN];   // bias of the wave's columns, requested once per tile
 #pragma unroll
-    for (int jg = 0; jg < TM / 4; ++jg)
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int m = m0 + wm * WM + jg * 64 + it * 8 + srow;
-        auxv[jg][it] = i32x4_t{0, 0, 0, 0};
-        if (m < p.M && col_ok) auxv[jg][it] = *(const i32x4_t*)(p.aux_in + (size_t)m * p.ldx + nw + sch * 8);
-      }
+  for (int i = 0; i < TN; ++i) {
+    const int n = nw + i * 16 + g * 4;
+    bvs[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (p.bias && n < p.N) bvs[i] = *(const f32x4_t*)(p.bias + n);
   }
 #pragma unroll
   for (int jg = 0; jg < TM / 4; ++jg) {
     const int mrow0 = m0 + wm * WM + jg * 64;
     if (mrow0 >= p.M) break;  // wave-uniform
+    // ---- (A) saved pre-activation / derivative for the backward epilogues: HBM -> patch (coalesced; the group's
+    // eight loads are in flight together — requesting both groups up front costs 64 registers and spills) ----
     if (has_aux) {
+      i32x4_t auxv[8];
 #pragma unroll
-      for (int it = 0; it < 8; ++it) *(i32x4_t*)(patch + (it * 8 + srow) * PITCH + sch * 16) = auxv[jg][it];
+      for (int it = 0; it < 8; ++it) {
+        const int m = mrow0 + it * 8 + srow;
+        auxv[it] = i32x4_t{0, 0, 0, 0};
+        if (m < p.M && col_ok) auxv[it] = *(const i32x4_t*)(p.aux_in + (size_t)m * p.ldx + nw + sch * 8);
+      }
+#pragma unroll
+      for (int it = 0; it < 8; ++it) *(i32x4_t*)(patch + (it * 8 + srow) * PITCH + sch * 16) = auxv[it];
     }
     // ---- (B) bias, derivative / pre-activation ----
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
-      const int n = nw + i * 16 + g * 4;
-      f32x4_t bv = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      if (p.bias && n < p.N) bv = *(const f32x4_t*)(p.bias + n);
+      const f32x4_t bv = bvs[i];
 #pragma unroll
       for (int jl = 0; jl < 4; ++jl) {
         f32x4_t v = acc[i][jg * 4 + jl] + bv;
@@ -158,6 +199,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmNtArgs& p, f32x4_t (
           }
           i32x2_t pk = {(int)pack_bf16x2(d[0], d[1]), (int)pack_bf16x2(d[2], d[3])};
           *(i32x2_t*)(patch + (jl * 16 + frow) * PITCH + (i * 16 + g * 4) * 2) = pk;
+          __builtin_amdgcn_sched_barrier(0);   // one sub-tile's sigmoid temporaries at a time (64 of them spill)
         } else if (act == LC2IS_ACT_DQUICK_GELU || act == LC2IS_ACT_DRELU || act == LC2IS_ACT_MUL_AUX) {
           const i32x2_t zk = *(const i32x2_t*)(patch + (jl * 16 + frow) * PITCH + (i * 16 + g * 4) * 2);
           float z[4] = {bf16_to_f32((bf16_t)(zk[0] & 0xffff)), bf16_to_f32((bf16_t)((unsigned)zk[0] >> 16)),
@@ -197,26 +239,43 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmNtArgs& p, f32x4_t (
       }
     }
     // ---- (D) activation, fp32 residual / output (direct), (E) bf16 output through the patch ----
+    // residual rows are requested one sub-tile column (4 loads) ahead of their first store: the outputs may alias
+    // them (in-place residual), so the compiler will not hoist the loads itself, and more in flight would spill
+    constexpr int RPF = 1;
+    static_assert(TN % RPF == 0, "staged epilogue walks sub-tile columns in groups of RPF");
 #pragma unroll
-    for (int i = 0; i < TN; ++i) {
-      const int n = nw + i * 16 + g * 4;
+    for (int ip = 0; ip < TN; ip += RPF) {
+      f32x4_t rv[RPF][4];
 #pragma unroll
-      for (int jl = 0; jl < 4; ++jl) {
-        const int m = mrow0 + jl * 16 + frow;
-        f32x4_t v = acc[i][jg * 4 + jl];
-        if (act == LC2IS_ACT_QUICK_GELU) {
+      for (int ii = 0; ii < RPF; ++ii)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = v[r] * sigmoidf_fast(1.702f * v[r]);
-        } else if (act == LC2IS_ACT_RELU) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        for (int jl = 0; jl < 4; ++jl) {
+          const int n = nw + (ip + ii) * 16 + g * 4, m = mrow0 + jl * 16 + frow;
+          rv[ii][jl] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+          if (p.resid && m < p.M && n < p.N) rv[ii][jl] = *(const f32x4_t*)(p.resid + (size_t)m * p.ldr + n);
         }
-        const bool ok = (m < p.M) && (n < p.N);
-        if (p.resid && ok) v += *(const f32x4_t*)(p.resid + (size_t)m * p.ldr + n);
-        if (p.out_f32 && ok) __builtin_nontemporal_store(v, (f32x4_t*)(p.out_f32 + (size_t)m * p.ldf + n));
-        if (p.out_bf16) {
-          i32x2_t pk = {(int)pack_bf16x2(v[0], v[1]), (int)pack_bf16x2(v[2], v[3])};
-          *(i32x2_t*)(patch + (jl * 16 + frow) * PITCH + (i * 16 + g * 4) * 2) = pk;
+#pragma unroll
+      for (int ii = 0; ii < RPF; ++ii) {
+        const int i = ip + ii;
+        const int n = nw + i * 16 + g * 4;
+#pragma unroll
+        for (int jl = 0; jl < 4; ++jl) {
+          const int m = mrow0 + jl * 16 + frow;
+          f32x4_t v = acc[i][jg * 4 + jl];
+          if (act == LC2IS_ACT_QUICK_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = v[r] * sigmoidf_fast(1.702f * v[r]);
+          } else if (act == LC2IS_ACT_RELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+          }
+          const bool ok = (m < p.M) && (n < p.N);
+          v += rv[ii][jl];
+          if (p.out_f32 && ok) __builtin_nontemporal_store(v, (f32x4_t*)(p.out_f32 + (size_t)m * p.ldf + n));
+          if (p.out_bf16) {
+            i32x2_t pk = {(int)pack_bf16x2(v[0], v[1]), (int)pack_bf16x2(v[2], v[3])};
+            *(i32x2_t*)(patch + (jl * 16 + frow) * PITCH + (i * 16 + g * 4) * 2) = pk;
+          }
         }
       }
     }
@@ -229,6 +288,14 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmNtArgs& p, f32x4_t (
       }
     }
   }
+}
+
+template <int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void gemm_epilogue_lds(const GemmNtArgs& p, f32x4_t (&acc)[TN][TM], int m0, int n0, int wm,
+                                                  int wn, int lane, int wid, char* smem) {
+#define LC2IS_EPI_CALL(A) gemm_epilogue_lds_act<A, TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lane, wid, smem)
+  LC2IS_ACT_SWITCH(LC2IS_EPI_CALL)
+#undef LC2IS_EPI_CALL
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
@@ -448,10 +515,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_dma_kernel(Gemm
     if (sacc == 1.2345e30f && p.out_f32) p.out_f32[0] = sacc;
     return;
   }
-  if (p.staged_epi)
-    gemm_epilogue_lds<TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lane, wid, smem);
-  else
-    gemm_epilogue<TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lane);
+  if constexpr (WN == 64 && TM % 4 == 0) {
+    if (p.staged_epi) {
+      gemm_epilogue_lds<TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lane, wid, smem);
+      return;
+    }
+  }
+  gemm_epilogue<TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lane);
 }
 
 // ---- ping-pong variant: the two waves of every SIMD alternate LDS-read and MFMA segments ------------------
@@ -849,6 +919,28 @@ int launch_pp(const GemmNtArgs& a, hipStream_t stream) {
   return lc2is_check_launch();
 }
 
+int launch_by_cfg(const GemmNtArgs& a, int cfg, hipStream_t stream) {
+  switch (cfg) {
+    case 1: return launch_cfg<128, 128, 2, 2>(a, stream);
+    case 2: return launch_cfg<256, 128, 4, 2>(a, stream);
+    case 3: return launch_cfg<64, 64, 2, 2>(a, stream);
+    case 4: return launch_dma<256, 256, 2, 4>(a, stream);
+    case 5: return launch_dma<256, 128, 4, 2>(a, stream);
+    case 6: return launch_dma<128, 128, 2, 2>(a, stream);
+    case 7: return launch_pp(a, stream);
+    case 8: return launch_ring(a, stream);
+    case 9: return launch_duo(a, stream);
+    case 10: return launch_dma<128, 384, 2, 4>(a, stream);   // N = 768 / 2304: 3/4-size tiles, 64x96 per wave
+    // diagnostic ablations of cfg 4 (wrong results by design; tools/gemm_ablate.py only)
+    case 41: return launch_dma<256, 256, 2, 4, 1>(a, stream);
+    case 42: return launch_dma<256, 256, 2, 4, 2>(a, stream);
+    case 43: return launch_dma<256, 256, 2, 4, 3>(a, stream);
+    case 45: return launch_dma<256, 256, 2, 4, 5>(a, stream);
+    case 47: return launch_dma<256, 256, 2, 4, 7>(a, stream);
+    default: return LC2IS_ERR_UNSUPPORTED;
+  }
+}
+
 }  // namespace
 
 extern "C" int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw, const float* bias,
@@ -874,29 +966,44 @@ extern "C" int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw
   a.staged_epi = (N % 8 == 0) && (!out_bf16 || ldo % 8 == 0) && (!aux_out || ldy % 8 == 0) &&
                  (!aux_in || ldx % 8 == 0) && (out_bf16 || aux_out || aux_in);
   int cfg = tile_cfg;
-  if (cfg == 0) {
-    const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-    if (tiles128 >= 1024 && N % 256 == 0) cfg = 4;       // plenty of work: 256x256 LDS-DMA tiles
+  if (cfg != 0) return launch_by_cfg(a, cfg, stream);
+  const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+  if (!(tiles128 >= 1024 && N % 256 == 0)) {
+    if (tiles128 >= 1024 && N % 256 == 0) cfg = 4;
     else if (tiles128 >= 512) cfg = 6;                   // 128x128 LDS-DMA tiles, 2 blocks/CU
     else if (tiles128 >= 128) cfg = 1;
     else cfg = 3;                                        // small problem: 64x64 tiles to fill the chip
+    return launch_by_cfg(a, cfg, stream);
   }
-  switch (cfg) {
-    case 1: return launch_cfg<128, 128, 2, 2>(a, stream);
-    case 2: return launch_cfg<256, 128, 4, 2>(a, stream);
-    case 3: return launch_cfg<64, 64, 2, 2>(a, stream);
-    case 4: return launch_dma<256, 256, 2, 4>(a, stream);
-    case 5: return launch_dma<256, 128, 4, 2>(a, stream);
-    case 6: return launch_dma<128, 128, 2, 2>(a, stream);
-    case 7: return launch_pp(a, stream);
-    case 8: return launch_ring(a, stream);
-    case 9: return launch_duo(a, stream);
-    // diagnostic ablations of cfg 4 (wrong results by design; tools/gemm_ablate.py only)
-    case 41: return launch_dma<256, 256, 2, 4, 1>(a, stream);
-    case 42: return launch_dma<256, 256, 2, 4, 2>(a, stream);
-    case 43: return launch_dma<256, 256, 2, 4, 3>(a, stream);
-    case 45: return launch_dma<256, 256, 2, 4, 5>(a, stream);
-    case 47: return launch_dma<256, 256, 2, 4, 7>(a, stream);
-    default: return LC2IS_ERR_UNSUPPORTED;
-  }
+  // Plenty of work: 256x256 LDS-DMA tiles, one block per CU, so time = rounds x tile cost; the ragged last <= 64 rows
+  // (B x 1025 tokens: 32 rows) are peeled off into a small-tile launch when that saves a whole round of tiles.
+  int best_cfg = 0, best_main = M;
+  double best_cost = 1e300;
+  for (int split = 0; split < 2; ++split)
+    for (int c : {4}) {   // 10 (128x384) measured ~45 % slower per flop than 256x256: kept for experiments only
+      const int bm = c == 4 ? 256 : 128, bn = c == 4 ? 256 : 384;
+      if (N % bn) continue;
+      const int r = M % bm;
+      if (split && (r == 0 || r > 64 || M <= bm)) continue;
+      const int mm = split ? M - r : M;
+      const long tiles = (long)((mm + bm - 1) / bm) * (N / bn);
+      double cost = (double)((tiles + 255) / 256) * bm * bn * (c == 10 ? 1.04 : 1.0);   // 4/3 of the L2->LDS traffic
+      if (split) cost += 65536.0 * 0.3 * 768.0 / K;                                      // ~8 us for the extra launch
+      if (c != 4 || split) cost *= 1.03;                                                 // prefer the plain plan on near-ties
+      if (cost < best_cost) { best_cost = cost; best_cfg = c; best_main = mm; }
+    }
+  if (best_main == M) return launch_by_cfg(a, best_cfg, stream);
+  GemmNtArgs main_part = a, tail = a;
+  main_part.M = best_main;
+  int rc = launch_by_cfg(main_part, best_cfg, stream);
+  if (rc) return rc;
+  const size_t m0 = (size_t)best_main;
+  tail.M = M - best_main;
+  tail.A = a.A + m0 * lda;
+  if (a.resid) tail.resid = a.resid + m0 * ldr;
+  if (a.aux_in) tail.aux_in = a.aux_in + m0 * ldx;
+  if (a.out_bf16) tail.out_bf16 = a.out_bf16 + m0 * ldo;
+  if (a.out_f32) tail.out_f32 = a.out_f32 + m0 * ldf;
+  if (a.aux_out) tail.aux_out = a.aux_out + m0 * ldy;
+  return launch_by_cfg(tail, 3, stream);
 }

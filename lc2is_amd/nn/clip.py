@@ -170,9 +170,9 @@ def _stack_fwd(x, stack: _Stack, sh, a: ClipArch, B: int, S: int, kbias, causal:
         _, x_mid, _ = ops.gemm_nt(o, s["wo"], layer.self_attn.out_proj.bias, resid=x, out_bf16=None, out_f32=True)
         h2, _, m2, r2 = ops.layernorm_fwd(x_mid, layer.layer_norm2.weight, layer.layer_norm2.bias, a.eps,
                                           save_stats=save)
-        # z: quick_gelu'(fc1 pre-activation) in bf16 — the fc2-dgrad epilogue then only multiplies (no exp/rcp there)
-        act, _, z = ops.gemm_nt(h2, s["w1"], layer.mlp.fc1.bias, act=ops.ACT_QUICK_GELU_GRAD if save else ops.ACT_QUICK_GELU,
-                                aux_out=True if save else None)
+        # (codes 5/6 — save quick_gelu'(z), multiply in the backward — exist in the C ABI; the pair measured 4 % slower
+        #  end to end than saving z: the forward variant's sigmoid temporaries spill beside the 128 accumulators)
+        act, _, z = ops.gemm_nt(h2, s["w1"], layer.mlp.fc1.bias, act=ops.ACT_QUICK_GELU, aux_out=True if save else None)
         _, x_out, _ = ops.gemm_nt(act, s["w2"], layer.mlp.fc2.bias, resid=x_mid, out_bf16=None, out_f32=True)
         if save:
             saved.append((x, m1, r1, h, qkv, o, lse, x_mid, m2, r2, h2, z, act))
@@ -191,7 +191,7 @@ def _stack_bwd(g32, g16, stack: _Stack, sh, saved, a: ClipArch, B: int, S: int, 
         at, mlp = layer.self_attn, layer.mlp
         # x_out = x_mid + fc2(quick_gelu(fc1(LN2(x_mid))))
         linear_bwd_params(g16, act, mlp.fc2.weight, mlp.fc2.bias)
-        dz, _, _ = ops.gemm_nt(g16, s["w2T"], None, act=ops.ACT_MUL_AUX, aux_in=z)
+        dz, _, _ = ops.gemm_nt(g16, s["w2T"], None, act=ops.ACT_DQUICK_GELU, aux_in=z)
         linear_bwd_params(dz, h2, mlp.fc1.weight, mlp.fc1.bias)
         dh2, _, _ = ops.gemm_nt(dz, s["w1T"], None)
         dg, accg = vec_grad(layer.layer_norm2.weight)

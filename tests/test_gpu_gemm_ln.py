@@ -43,7 +43,7 @@ def test_gemm_nt_asymmetric_identity(dev):
     assert torch.equal(of, w.float().T.contiguous())
 
 
-@pytest.mark.parametrize("cfg", [0, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("cfg", [0, 4, 5, 6, 7, 8, 10])
 @pytest.mark.parametrize("act", ["quick_gelu", "relu"])
 def test_gemm_nt_activation_and_backward_epilogue(dev, act, cfg):
     from lc2is_amd import ops
@@ -73,6 +73,30 @@ def test_gemm_nt_activation_and_backward_epilogue(dev, act, cfg):
         d = (s > 0).double()
     ref = (dy.double() @ w.double().T) * d
     assert _rel(dz.float(), ref) < 5e-3
+
+
+@pytest.mark.parametrize("N,K", [(3072, 128), (768, 192), (2304, 128)])
+def test_gemm_nt_auto_plan_ragged_rows(dev, N, K):
+    """M = 64*256 + 32 rows (the B x 1025-token shape): the automatic plan peels the ragged rows into a small-tile
+    launch and / or picks 128x384 tiles; every output must match the single-launch 256x256 plan."""
+    from lc2is_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(N + K)
+    M = 64 * 256 + 32
+    a = _bf(torch.randn(M, K, generator=g)).to(dev)
+    w = _bf(torch.randn(N, K, generator=g) * 0.1).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    resid = torch.randn(M, N, generator=g).to(dev)
+    outs = {}
+    for cfg in (4, 0):
+        ob, of, d = ops.gemm_nt(a, w, bias, act=ops.ACT_QUICK_GELU_GRAD, resid=resid, out_bf16=True, out_f32=True,
+                                aux_out=True, tile_cfg=cfg)
+        dz, _, _ = ops.gemm_nt(a, w, None, act=ops.ACT_MUL_AUX, aux_in=d, tile_cfg=cfg)
+        outs[cfg] = (ob.float(), of, d.float(), dz.float())
+    for x, y in zip(outs[0], outs[4]):
+        assert _rel(x, y.double()) < 1e-6
+    ref = a[-40:].double() @ w.double().T + bias.double()
+    sg = torch.sigmoid(1.702 * ref)
+    assert _rel(outs[0][1][-40:], ref * sg + resid[-40:].double()) < 1e-5      # the peeled rows themselves
 
 
 @pytest.mark.parametrize("cfg", [0, 3, 4, 9])
