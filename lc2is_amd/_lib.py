@@ -12,7 +12,7 @@ import re
 from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
-_SO = _PKG / "liblc2is_hip.so"
+_SO = Path(os.environ.get("LC2IS_LIB", _PKG / "liblc2is_hip.so"))   # LC2IS_LIB: A/B an alternative build of the same ABI
 _HEADER = _PKG.parent / "include" / "lc2is_hip.h"
 
 _ERR = {
