@@ -31,6 +31,8 @@ extern "C" {
 #define LC2IS_ACT_QUICK_GELU_GRAD 5 /* forward: out = quick_gelu(z), aux_out = quick_gelu'(z) (bf16) — saves the
                                       backward's transcendentals; pair with LC2IS_ACT_MUL_AUX            */
 #define LC2IS_ACT_MUL_AUX 6     /* backward: acc * aux_in (aux_in = the derivative saved by code 5)     */
+#define LC2IS_ACT_GELU_ERF 7    /* exact GELU 0.5x(1+erf(x/sqrt2)), hf:activations.py "gelu" (Swin MLP) */
+#define LC2IS_ACT_DGELU_ERF 8   /* backward: acc * gelu'(aux_in)                                         */
 
 #define LC2IS_INTERP_BICUBIC 0  /* F.interpolate(mode="bicubic", align_corners=False), A = -0.75, border clamp */
 #define LC2IS_INTERP_BILINEAR 1 /* F.interpolate(mode="bilinear", align_corners=False)                          */
@@ -208,6 +210,27 @@ int lc2is_l2norm_bwd(const float* dy, const float* x, const float* inv_norm, flo
 /* out = a + b (+ c) (+ d)  — torch.stack(...).sum(0) of model/hierarchical.py:128-129. */
 int lc2is_add_n(const float* a, const float* b, const float* c, const float* d, float* out_f32, void* out_bf16,
                 size_t n, lc2is_stream_t stream);
+
+/* ---- Swin backbone (model/encoder.py:121-131 -> hf:models/swin/modeling_swin.py) ---------------------------------
+ * rows_gather: dst[r][0:cols] = (map[r] >= 0 ? src[map[r]][0:cols] : 0) (+ add[r][0:cols]); src/dst fp32 or bf16
+ *   (flags), add fp32.  With host-built index maps this is pad + cyclic shift + window partition
+ *   (modeling_swin.py:546-550), window reverse + un-shift + un-pad + residual add (:558-567), the patch-merging 2x2
+ *   concat (:318-321) and each of their backwards (inverse maps). */
+int lc2is_rows_gather(const void* src, int ld_src, int src_bf16, void* dst, int ld_dst, int dst_bf16, const int* map,
+                      const float* add, int ld_add, int rows, int cols, lc2is_stream_t stream);
+/* Window attention (modeling_swin.py:373-398,428-465): qkv [nwin*S, 3C] bf16 (q | k | v, head h at columns 32h),
+ *   S = ws*ws <= 64, head_dim 32, bias [nH,S,S] fp32 = relative position bias; for shift > 0 the cyclic-shift region
+ *   mask (-100 across regions, :584-607) is derived from the window index (win_per_img windows per image, nwx per
+ *   row, padded grid Hp x Wp).  out [nwin*S, C] bf16, lse [nwin,nH,S].  Backward writes dqkv and the bias gradient
+ *   dbias [nH,S,S] (summed over windows in a fixed order; workspace from the _workspace_bytes call). */
+int lc2is_swin_attn_fwd(const void* qkv, int ld, void* out, int ldo, float* lse, const float* bias, int nwin,
+                        int win_per_img, int nwx, int Hp, int Wp, int ws, int shift, int nH, int C, float scale,
+                        lc2is_stream_t stream);
+size_t lc2is_swin_attn_bwd_workspace_bytes(int nwin, int ws, int nH);
+int lc2is_swin_attn_bwd(const void* qkv, int ld, const void* o, int ld_o, const void* dout, int lddo, const float* lse,
+                        const float* bias, void* dqkv, int lddq, float* dbias, int accumulate_dbias, int nwin,
+                        int win_per_img, int nwx, int Hp, int Wp, int ws, int shift, int nH, int C, float scale,
+                        void* workspace, size_t workspace_bytes, lc2is_stream_t stream);
 
 /* ---- remaining losses (model/loss.py) and the parity metric (metrics.py) on channels-last scores ----------
  * rows_ce: softmax-CE over the K contiguous classes of each of M rows: loss_sum[0] += sum of per-row losses,

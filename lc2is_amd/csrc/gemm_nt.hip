@@ -36,6 +36,11 @@ struct GemmNtArgs {
 };
 
 __device__ __forceinline__ float sigmoidf_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }  // v_exp + v_rcp
+// exact GELU of hf:activations.py "gelu" (Swin MLP, modeling_swin.py:474): 0.5 x (1 + erf(x / sqrt 2)) and its derivative
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_erf(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+}
 
 // The activation code is a template parameter of both epilogues: with a run-time `act` inside the unrolled sub-tile
 // loops the kernels carried every variant inline (25k instructions for the 256x256 kernel, more than the instruction
@@ -53,7 +58,8 @@ __device__ __forceinline__ void gemm_epilogue_act(const GemmNtArgs& p, f32x4_t (
     if (p.bias) bv = *(const f32x4_t*)(p.bias + n);
     // every load of this column of sub-tiles is issued before its first store: the outputs may alias the inputs
     // (in-place residual), so the compiler will not hoist them itself and each sub-tile would pay a full load latency
-    constexpr bool kAux = act == LC2IS_ACT_DQUICK_GELU || act == LC2IS_ACT_DRELU || act == LC2IS_ACT_MUL_AUX;
+    constexpr bool kAux = act == LC2IS_ACT_DQUICK_GELU || act == LC2IS_ACT_DRELU || act == LC2IS_ACT_MUL_AUX ||
+                          act == LC2IS_ACT_DGELU_ERF;
     constexpr int PF = TM < 4 ? TM : 4;   // sub-tiles prefetched together (more would spill beside 128 accumulators)
 #pragma unroll
     for (int j0 = 0; j0 < TM; j0 += PF) {
@@ -87,14 +93,15 @@ __device__ __forceinline__ void gemm_epilogue_act(const GemmNtArgs& p, f32x4_t (
           i32x2_t pk = {(int)pack_bf16x2(d[0], d[1]), (int)pack_bf16x2(d[2], d[3])};
           *(i32x2_t*)(p.aux_out + (size_t)m * p.ldy + n) = pk;
         }
-      } else if (act == LC2IS_ACT_QUICK_GELU || act == LC2IS_ACT_RELU) {
+      } else if (act == LC2IS_ACT_QUICK_GELU || act == LC2IS_ACT_RELU || act == LC2IS_ACT_GELU_ERF) {
         if (p.aux_out) {
           i32x2_t pk = {(int)pack_bf16x2(v[0], v[1]), (int)pack_bf16x2(v[2], v[3])};
           *(i32x2_t*)(p.aux_out + (size_t)m * p.ldy + n) = pk;
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          v[r] = (act == LC2IS_ACT_RELU) ? fmaxf(v[r], 0.f) : v[r] * sigmoidf_fast(1.702f * v[r]);
+          v[r] = (act == LC2IS_ACT_RELU) ? fmaxf(v[r], 0.f)
+                                         : (act == LC2IS_ACT_GELU_ERF ? gelu_erf(v[r]) : v[r] * sigmoidf_fast(1.702f * v[r]));
       } else if (kAux) {
         const i32x2_t zk = zv[jj];
         float z[4] = {bf16_to_f32((bf16_t)(zk[0] & 0xffff)), bf16_to_f32((bf16_t)((unsigned)zk[0] >> 16)),
@@ -105,6 +112,8 @@ __device__ __forceinline__ void gemm_epilogue_act(const GemmNtArgs& p, f32x4_t (
             v[r] *= z[r];
           } else if (act == LC2IS_ACT_DRELU) {
             v[r] = z[r] > 0.f ? v[r] : 0.f;
+          } else if (act == LC2IS_ACT_DGELU_ERF) {
+            v[r] *= dgelu_erf(z[r]);
           } else {
             const float s = sigmoidf_fast(1.702f * z[r]);
             v[r] *= s * (1.f + 1.702f * z[r] * (1.f - s));
@@ -130,6 +139,8 @@ __device__ __forceinline__ void gemm_epilogue_act(const GemmNtArgs& p, f32x4_t (
     case LC2IS_ACT_DRELU: CALL(LC2IS_ACT_DRELU); break;                       \
     case LC2IS_ACT_QUICK_GELU_GRAD: CALL(LC2IS_ACT_QUICK_GELU_GRAD); break;   \
     case LC2IS_ACT_MUL_AUX: CALL(LC2IS_ACT_MUL_AUX); break;                   \
+    case LC2IS_ACT_GELU_ERF: CALL(LC2IS_ACT_GELU_ERF); break;                 \
+    case LC2IS_ACT_DGELU_ERF: CALL(LC2IS_ACT_DGELU_ERF); break;               \
     default: CALL(LC2IS_ACT_NONE); break;                                     \
   }
 
@@ -157,7 +168,8 @@ __device__ __forceinline__ void gemm_epilogue_lds_act(const GemmNtArgs& p, f32x4
   const int nw = n0 + wn * WN;
   const bool col_ok = (nw + sch * 8) < p.N;
 
-  constexpr bool has_aux = act == LC2IS_ACT_DQUICK_GELU || act == LC2IS_ACT_DRELU || act == LC2IS_ACT_MUL_AUX;
+  constexpr bool has_aux = act == LC2IS_ACT_DQUICK_GELU || act == LC2IS_ACT_DRELU || act == LC2IS_ACT_MUL_AUX ||
+                           act == LC2IS_ACT_DGELU_ERF;
   f32x4_t bvs[TN];   // bias of the wave's columns, requested once per tile
 #pragma unroll
   for (int i = 0; i < TN; ++i) {
@@ -200,7 +212,7 @@ __device__ __forceinline__ void gemm_epilogue_lds_act(const GemmNtArgs& p, f32x4
           i32x2_t pk = {(int)pack_bf16x2(d[0], d[1]), (int)pack_bf16x2(d[2], d[3])};
           *(i32x2_t*)(patch + (jl * 16 + frow) * PITCH + (i * 16 + g * 4) * 2) = pk;
           __builtin_amdgcn_sched_barrier(0);   // one sub-tile's sigmoid temporaries at a time (64 of them spill)
-        } else if (act == LC2IS_ACT_DQUICK_GELU || act == LC2IS_ACT_DRELU || act == LC2IS_ACT_MUL_AUX) {
+        } else if (has_aux) {
           const i32x2_t zk = *(const i32x2_t*)(patch + (jl * 16 + frow) * PITCH + (i * 16 + g * 4) * 2);
           float z[4] = {bf16_to_f32((bf16_t)(zk[0] & 0xffff)), bf16_to_f32((bf16_t)((unsigned)zk[0] >> 16)),
                         bf16_to_f32((bf16_t)(zk[1] & 0xffff)), bf16_to_f32((bf16_t)((unsigned)zk[1] >> 16))};
@@ -208,6 +220,8 @@ __device__ __forceinline__ void gemm_epilogue_lds_act(const GemmNtArgs& p, f32x4
           for (int r = 0; r < 4; ++r) {
             if (act == LC2IS_ACT_MUL_AUX) {
               v[r] *= z[r];
+            } else if (act == LC2IS_ACT_DGELU_ERF) {
+              v[r] *= dgelu_erf(z[r]);
             } else if (act == LC2IS_ACT_DRELU) {
               v[r] = z[r] > 0.f ? v[r] : 0.f;
             } else {
@@ -220,7 +234,8 @@ __device__ __forceinline__ void gemm_epilogue_lds_act(const GemmNtArgs& p, f32x4
       }
     }
     // ---- (C) store the pre-activation (bf16), or the derivative (B) left in the patch ----
-    if ((act == LC2IS_ACT_QUICK_GELU || act == LC2IS_ACT_RELU || act == LC2IS_ACT_QUICK_GELU_GRAD) && p.aux_out) {
+    if ((act == LC2IS_ACT_QUICK_GELU || act == LC2IS_ACT_RELU || act == LC2IS_ACT_QUICK_GELU_GRAD ||
+         act == LC2IS_ACT_GELU_ERF) && p.aux_out) {
       if (act != LC2IS_ACT_QUICK_GELU_GRAD) {
 #pragma unroll
         for (int i = 0; i < TN; ++i)
@@ -265,6 +280,9 @@ __device__ __forceinline__ void gemm_epilogue_lds_act(const GemmNtArgs& p, f32x4
           if (act == LC2IS_ACT_QUICK_GELU) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = v[r] * sigmoidf_fast(1.702f * v[r]);
+          } else if (act == LC2IS_ACT_GELU_ERF) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
           } else if (act == LC2IS_ACT_RELU) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
@@ -956,8 +974,9 @@ extern "C" int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw
   if ((out_bf16 && (ldo < N || ldo % 4)) || (out_f32 && (ldf < N || ldf % 4)) || (resid && (ldr < N || ldr % 4)) ||
       (aux_in && (ldx < N || ldx % 4)) || (aux_out && (ldy < N || ldy % 4)))
     return LC2IS_ERR_SHAPE;
-  if ((act == LC2IS_ACT_DQUICK_GELU || act == LC2IS_ACT_DRELU || act == LC2IS_ACT_MUL_AUX) && !aux_in) return LC2IS_ERR_NULL;
-  if (act < LC2IS_ACT_NONE || act > LC2IS_ACT_MUL_AUX) return LC2IS_ERR_UNSUPPORTED;
+  if ((act == LC2IS_ACT_DQUICK_GELU || act == LC2IS_ACT_DRELU || act == LC2IS_ACT_MUL_AUX || act == LC2IS_ACT_DGELU_ERF) && !aux_in)
+    return LC2IS_ERR_NULL;
+  if (act < LC2IS_ACT_NONE || act > LC2IS_ACT_DGELU_ERF) return LC2IS_ERR_UNSUPPORTED;
   // 32-bit buffer offsets: operand panels (plus one tile of overhang) must stay under 2 GiB
   if ((double)(M + 256) * lda * 2.0 >= 2147483648.0 || (double)(N + 256) * ldw * 2.0 >= 2147483648.0)
     return LC2IS_ERR_UNSUPPORTED;

@@ -1,0 +1,372 @@
+// Swin backbone kernels (model/encoder.py:121-131 -> hf:models/swin/modeling_swin.py).
+//   * rows_gather: dst[r] = (map[r] >= 0 ? src[map[r]] : 0) (+ add[r]) over token rows.  With index maps built once
+//     per (grid, window, shift) on the host side this one kernel is every re-layout of the path and its backward:
+//     pad + cyclic shift + window partition (modeling_swin.py:546-550), window reverse + un-shift + un-pad + the
+//     residual add (:558-567), and the 2x2 patch-merging concat (:318-321).  HBM-bound, 16-byte lanes.
+//   * window attention (modeling_swin.py:373-398, 428-465): one wave per (window, head); S = ws*ws <= 64 tokens,
+//     head_dim 32; lane i owns query row i, keys/values are broadcast from LDS; logits get the per-head relative
+//     position bias [nH, S, S] and, for shifted blocks, the region mask computed from the window's position
+//     (-100 where the 3x3 cyclic-shift regions of query and key differ, :584-607).  fp32 math, bf16 I/O.
+//     Backward: pass A (lane = query) forms P and dS in LDS and dQ; pass B (lane = key) reads their columns for
+//     dK, dV; dS is accumulated per (head, window-chunk) in LDS in window order and written as partials that a second
+//     launch sums in chunk order (bias-table gradient, bitwise reproducible, no atomics).
+//   These tiny-tile attentions are latency/HBM-bound (16 MFMA-tiles of work per wave), so round 1 keeps them on the
+//   VALU; the GEMMs of the blocks run on the shared MFMA kernels.
+#include "common.h"
+#include "lc2is_hip.h"
+
+namespace {
+
+constexpr int SW_D = 32;      // head_dim of every Swin variant (96/3, 128/4, 192/6 ...)
+constexpr int SW_MAXS = 64;   // window tokens <= one wave
+
+// LDS traffic of ONE wave is in order; this only stops the compiler from moving accesses across the hand-off point
+#define SW_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+// ---- generic row gather ------------------------------------------------------------------------------------------
+template <bool SRC_BF16, bool DST_BF16>
+__global__ __launch_bounds__(256) void rows_gather_kernel(const void* __restrict__ src_, int ld_src, void* dst_,
+                                                           int ld_dst, const int* __restrict__ map,
+                                                           const float* __restrict__ add, int ld_add, int rows,
+                                                           int cols) {
+  const int c4 = cols >> 2;  // 4-element groups per row
+  const size_t total = (size_t)rows * c4;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int r = (int)(idx / c4), c = (int)(idx % c4) * 4;
+    const int s = map[r];
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (s >= 0) {
+      if (SRC_BF16) {
+        const i32x2_t pk = *(const i32x2_t*)((const bf16_t*)src_ + (size_t)s * ld_src + c);
+        v[0] = bf16_to_f32((bf16_t)(pk[0] & 0xffff)); v[1] = bf16_to_f32((bf16_t)((unsigned)pk[0] >> 16));
+        v[2] = bf16_to_f32((bf16_t)(pk[1] & 0xffff)); v[3] = bf16_to_f32((bf16_t)((unsigned)pk[1] >> 16));
+      } else {
+        const f32x4_t f = *(const f32x4_t*)((const float*)src_ + (size_t)s * ld_src + c);
+        v[0] = f[0]; v[1] = f[1]; v[2] = f[2]; v[3] = f[3];
+      }
+    }
+    if (add) {
+      const f32x4_t a = *(const f32x4_t*)(add + (size_t)r * ld_add + c);
+      v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3];
+    }
+    if (DST_BF16) {
+      i32x2_t pk = {(int)pack_bf16x2(v[0], v[1]), (int)pack_bf16x2(v[2], v[3])};
+      *(i32x2_t*)((bf16_t*)dst_ + (size_t)r * ld_dst + c) = pk;
+    } else {
+      *(f32x4_t*)((float*)dst_ + (size_t)r * ld_dst + c) = f32x4_t{v[0], v[1], v[2], v[3]};
+    }
+  }
+}
+
+// ---- window attention ----------------------------------------------------------------------------------------------
+struct SwinAttnArgs {
+  const bf16_t* qkv; int ld;       // [nwin*S, 3C]: q | k | v, head h at columns h*32
+  bf16_t* out; int ldo;            // forward: o [nwin*S, C]
+  float* lse;                      // [nwin, nH, S]
+  const float* bias;               // [nH, S, S]
+  const bf16_t* dout; int lddo;    // backward: dO, O
+  const bf16_t* o; int ld_o;
+  bf16_t* dqkv; int lddq;          // [nwin*S, 3C]
+  float* dbias_part;               // [nchunk, nH, S, S]
+  int nwin, win_per_img, nwx, Hp, Wp, ws, shift, nH, C, chunk;
+  float scale;
+};
+
+__device__ __forceinline__ int sw_region(int p, int extent, int ws, int shift) {
+  return (p >= extent - ws) + (p >= extent - shift);
+}
+
+__device__ __forceinline__ void sw_load_row(const bf16_t* p, float* dst) {   // 32 bf16 -> 32 floats
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const i32x4_t pk = *(const i32x4_t*)(p + 8 * k);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      dst[8 * k + 2 * e] = bf16_to_f32((bf16_t)(pk[e] & 0xffff));
+      dst[8 * k + 2 * e + 1] = bf16_to_f32((bf16_t)((unsigned)pk[e] >> 16));
+    }
+  }
+}
+
+__device__ __forceinline__ void sw_store_row(bf16_t* p, const float* v) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    i32x4_t pk;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pk[e] = (int)pack_bf16x2(v[8 * k + 2 * e], v[8 * k + 2 * e + 1]);
+    *(i32x4_t*)(p + 8 * k) = pk;
+  }
+}
+
+// forward: block = 4 waves, wave w handles pair (window, head) = blockIdx*4 + w
+__global__ __launch_bounds__(256) void swin_attn_fwd_kernel(SwinAttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int S = a.ws * a.ws;
+  const long pair = (long)blockIdx.x * 4 + wv;
+  if (pair >= (long)a.nwin * a.nH) return;   // whole wave exits (no block-wide barrier below)
+  const int win = (int)(pair / a.nH), h = (int)(pair % a.nH);
+  float* Ks = (float*)smem + (size_t)wv * 2 * SW_MAXS * SW_D;
+  float* Vs = Ks + SW_MAXS * SW_D;
+  const bool act = lane < S;
+  const size_t row = (size_t)win * S + (act ? lane : 0);
+  float q[SW_D];
+  {
+    float t[SW_D];
+    sw_load_row(a.qkv + row * a.ld + h * SW_D, q);
+    sw_load_row(a.qkv + row * a.ld + a.C + h * SW_D, t);
+    if (act) {
+#pragma unroll
+      for (int d = 0; d < SW_D; ++d) Ks[lane * SW_D + d] = t[d];
+    }
+    sw_load_row(a.qkv + row * a.ld + 2 * a.C + h * SW_D, t);
+    if (act) {
+#pragma unroll
+      for (int d = 0; d < SW_D; ++d) Vs[lane * SW_D + d] = t[d];
+    }
+  }
+  SW_LDS_SYNC();  // this wave's LDS writes have landed (single-wave producer/consumer, no block barrier)
+  // shifted-window mask: region ids in the shifted, padded frame
+  const int widx = win % a.win_per_img, wy = widx / a.nwx, wx = widx % a.nwx;
+  const int iy = (act ? lane : 0) / a.ws, ix = (act ? lane : 0) % a.ws;
+  const int rid = a.shift > 0 ? sw_region(wy * a.ws + iy, a.Hp, a.ws, a.shift) * 3 + sw_region(wx * a.ws + ix, a.Wp, a.ws, a.shift) : 0;
+  const float* brow = a.bias + ((size_t)h * S + (act ? lane : 0)) * S;
+  float m = -__builtin_inff(), l = 0.f, o[SW_D];
+#pragma unroll
+  for (int d = 0; d < SW_D; ++d) o[d] = 0.f;
+  for (int j = 0; j < S; ++j) {
+    const float* kj = Ks + j * SW_D;
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < SW_D; ++d) s += q[d] * kj[d];
+    s = s * a.scale + brow[j];
+    if (a.shift > 0) {
+      const int rj = sw_region(wy * a.ws + j / a.ws, a.Hp, a.ws, a.shift) * 3 + sw_region(wx * a.ws + j % a.ws, a.Wp, a.ws, a.shift);
+      if (rj != rid) s += -100.0f;
+    }
+    const float mn = fmaxf(m, s);
+    const float corr = __expf(m - mn), p = __expf(s - mn);
+    l = l * corr + p;
+    const float* vj = Vs + j * SW_D;
+#pragma unroll
+    for (int d = 0; d < SW_D; ++d) o[d] = o[d] * corr + p * vj[d];
+    m = mn;
+  }
+  if (act) {
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int d = 0; d < SW_D; ++d) o[d] *= inv;
+    sw_store_row(a.out + row * a.ldo + h * SW_D, o);
+    if (a.lse) a.lse[((size_t)win * a.nH + h) * S + lane] = m + __logf(l);
+  }
+}
+
+// backward: one wave per block; block (h, chunk) walks the windows of its chunk in order
+__global__ __launch_bounds__(64) void swin_attn_bwd_kernel(SwinAttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x;
+  const int S = a.ws * a.ws;
+  const int h = blockIdx.x % a.nH, chunk = blockIdx.x / a.nH;
+  float* Qs = (float*)smem;                    // [S][32] each
+  float* Ks = Qs + SW_MAXS * SW_D;
+  float* Vs = Ks + SW_MAXS * SW_D;
+  float* Ds = Vs + SW_MAXS * SW_D;             // dO
+  float* Pm = Ds + SW_MAXS * SW_D;             // [S][S+1]
+  float* Sm = Pm + SW_MAXS * (SW_MAXS + 1);    // dS
+  float* Acc = Sm + SW_MAXS * (SW_MAXS + 1);   // [S][S+1] bias-gradient accumulator of this block
+  const int PS = S + 1;
+  const bool act = lane < S;
+  for (int j = 0; j < S; ++j)
+    if (act) Acc[lane * PS + j] = 0.f;
+  const int w_begin = chunk * a.chunk;
+  int w_end = w_begin + a.chunk;
+  if (w_end > a.nwin) w_end = a.nwin;
+  const float* brow = a.bias + ((size_t)h * S + (act ? lane : 0)) * S;
+  for (int win = w_begin; win < w_end; ++win) {
+    const size_t row = (size_t)win * S + (act ? lane : 0);
+    float q[SW_D], dO[SW_D], kv[SW_D];
+    float delta = 0.f;
+    sw_load_row(a.qkv + row * a.ld + h * SW_D, q);
+    sw_load_row(a.dout + row * a.lddo + h * SW_D, dO);
+    {
+      float ov[SW_D];
+      sw_load_row(a.o + row * a.ld_o + h * SW_D, ov);
+#pragma unroll
+      for (int d = 0; d < SW_D; ++d) delta += dO[d] * ov[d];
+    }
+    SW_LDS_SYNC();   // previous window's pass B reads are done before its tiles are overwritten
+    sw_load_row(a.qkv + row * a.ld + a.C + h * SW_D, kv);
+    if (act) {
+#pragma unroll
+      for (int d = 0; d < SW_D; ++d) { Qs[lane * SW_D + d] = q[d]; Ks[lane * SW_D + d] = kv[d]; Ds[lane * SW_D + d] = dO[d]; }
+    }
+    sw_load_row(a.qkv + row * a.ld + 2 * a.C + h * SW_D, kv);
+    if (act) {
+#pragma unroll
+      for (int d = 0; d < SW_D; ++d) Vs[lane * SW_D + d] = kv[d];
+    }
+    SW_LDS_SYNC();
+    const float lse = act ? a.lse[((size_t)win * a.nH + h) * S + lane] : 0.f;
+    const int widx = win % a.win_per_img, wy = widx / a.nwx, wx = widx % a.nwx;
+    const int iy = (act ? lane : 0) / a.ws, ix = (act ? lane : 0) % a.ws;
+    const int rid = a.shift > 0 ? sw_region(wy * a.ws + iy, a.Hp, a.ws, a.shift) * 3 + sw_region(wx * a.ws + ix, a.Wp, a.ws, a.shift) : 0;
+    // ---- pass A: lane = query row ----
+    float dq[SW_D];
+#pragma unroll
+    for (int d = 0; d < SW_D; ++d) dq[d] = 0.f;
+    for (int j = 0; j < S; ++j) {
+      const float* kj = Ks + j * SW_D;
+      const float* vj = Vs + j * SW_D;
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < SW_D; ++d) { s += q[d] * kj[d]; dp += dO[d] * vj[d]; }
+      s = s * a.scale + brow[j];
+      if (a.shift > 0) {
+        const int rj = sw_region(wy * a.ws + j / a.ws, a.Hp, a.ws, a.shift) * 3 + sw_region(wx * a.ws + j % a.ws, a.Wp, a.ws, a.shift);
+        if (rj != rid) s += -100.0f;
+      }
+      const float p = __expf(s - lse);
+      const float ds = p * (dp - delta);
+      if (act) {
+        Pm[lane * PS + j] = p;
+        Sm[lane * PS + j] = ds;
+        Acc[lane * PS + j] += ds;
+      }
+      const float dss = ds * a.scale;
+#pragma unroll
+      for (int d = 0; d < SW_D; ++d) dq[d] += dss * kj[d];
+    }
+    if (act) sw_store_row(a.dqkv + row * a.lddq + h * SW_D, dq);
+    SW_LDS_SYNC();
+    // ---- pass B: lane = key row ----
+    float dk[SW_D], dv[SW_D];
+#pragma unroll
+    for (int d = 0; d < SW_D; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+    for (int i = 0; i < S; ++i) {
+      const float p = act ? Pm[i * PS + lane] : 0.f;
+      const float dss = (act ? Sm[i * PS + lane] : 0.f) * a.scale;
+      const float* qi = Qs + i * SW_D;
+      const float* di = Ds + i * SW_D;
+#pragma unroll
+      for (int d = 0; d < SW_D; ++d) { dk[d] += dss * qi[d]; dv[d] += p * di[d]; }
+    }
+    if (act) {
+      sw_store_row(a.dqkv + row * a.lddq + a.C + h * SW_D, dk);
+      sw_store_row(a.dqkv + row * a.lddq + 2 * a.C + h * SW_D, dv);
+    }
+  }
+  SW_LDS_SYNC();
+  if (a.dbias_part && act) {
+    float* dst = a.dbias_part + (((size_t)chunk * a.nH + h) * S + lane) * S;
+    for (int j = 0; j < S; ++j) dst[j] = Acc[lane * PS + j];
+  }
+}
+
+__global__ __launch_bounds__(256) void swin_dbias_reduce_kernel(const float* __restrict__ part, int nchunk, size_t n,
+                                                                 float* out, int accumulate) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int c = 0; c < nchunk; ++c) s += part[(size_t)c * n + i];
+  out[i] = accumulate ? out[i] + s : s;
+}
+
+inline int sw_chunks(int nwin, int nH) {
+  int nchunk = 2048 / (nH > 0 ? nH : 1);   // ~2048 single-wave blocks
+  if (nchunk < 1) nchunk = 1;
+  if (nchunk > nwin) nchunk = nwin;
+  return nchunk;
+}
+
+inline int sw_check(int nwin, int win_per_img, int nwx, int Hp, int Wp, int ws, int shift, int nH, int C) {
+  if (nwin <= 0 || win_per_img <= 0 || nwx <= 0 || ws <= 0 || nH <= 0) return LC2IS_ERR_SHAPE;
+  if (ws * ws > SW_MAXS || C != nH * SW_D) return LC2IS_ERR_UNSUPPORTED;
+  if (Hp % ws || Wp % ws || nwx != Wp / ws || win_per_img != (Hp / ws) * nwx || nwin % win_per_img) return LC2IS_ERR_SHAPE;
+  if (shift < 0 || shift >= ws) return LC2IS_ERR_SHAPE;
+  return LC2IS_OK;
+}
+
+}  // namespace
+
+extern "C" int lc2is_rows_gather(const void* src, int ld_src, int src_bf16, void* dst, int ld_dst, int dst_bf16,
+                                 const int* map, const float* add, int ld_add, int rows, int cols,
+                                 lc2is_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!src || !dst || !map) return LC2IS_ERR_NULL;
+  if (rows <= 0 || cols <= 0 || cols % 4 || ld_src < cols || ld_dst < cols || ld_src % 4 || ld_dst % 4) return LC2IS_ERR_SHAPE;
+  if (add && (ld_add < cols || ld_add % 4)) return LC2IS_ERR_SHAPE;
+  size_t g = ((size_t)rows * (cols / 4) + 255) / 256;
+  if (g > 16384) g = 16384;
+#define RG(SB, DB) hipLaunchKernelGGL((rows_gather_kernel<SB, DB>), dim3((int)g), dim3(256), 0, stream, src, ld_src, dst, \
+                                      ld_dst, map, add, ld_add, rows, cols)
+  if (src_bf16 && dst_bf16) RG(true, true);
+  else if (src_bf16) RG(true, false);
+  else if (dst_bf16) RG(false, true);
+  else RG(false, false);
+#undef RG
+  return lc2is_check_launch();
+}
+
+extern "C" int lc2is_swin_attn_fwd(const void* qkv, int ld, void* out, int ldo, float* lse, const float* bias, int nwin,
+                                   int win_per_img, int nwx, int Hp, int Wp, int ws, int shift, int nH, int C,
+                                   float scale, lc2is_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!qkv || !out || !bias) return LC2IS_ERR_NULL;
+  int rc = sw_check(nwin, win_per_img, nwx, Hp, Wp, ws, shift, nH, C);
+  if (rc) return rc;
+  if (ld < 3 * C || ldo < C || ld % 8 || ldo % 8) return LC2IS_ERR_SHAPE;
+  SwinAttnArgs a{};
+  a.qkv = (const bf16_t*)qkv; a.ld = ld; a.out = (bf16_t*)out; a.ldo = ldo; a.lse = lse; a.bias = bias;
+  a.nwin = nwin; a.win_per_img = win_per_img; a.nwx = nwx; a.Hp = Hp; a.Wp = Wp; a.ws = ws; a.shift = shift; a.nH = nH;
+  a.C = C; a.scale = scale;
+  const long pairs = (long)nwin * nH;
+  const int lds = 4 * 2 * SW_MAXS * SW_D * (int)sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)swin_attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return LC2IS_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(swin_attn_fwd_kernel, dim3((int)((pairs + 3) / 4)), dim3(256), lds, stream, a);
+  return lc2is_check_launch();
+}
+
+extern "C" size_t lc2is_swin_attn_bwd_workspace_bytes(int nwin, int ws, int nH) {
+  if (nwin <= 0 || ws <= 0 || nH <= 0) return 0;
+  return (size_t)sw_chunks(nwin, nH) * nH * ws * ws * ws * ws * sizeof(float);
+}
+
+extern "C" int lc2is_swin_attn_bwd(const void* qkv, int ld, const void* o, int ld_o, const void* dout, int lddo,
+                                   const float* lse, const float* bias, void* dqkv, int lddq, float* dbias,
+                                   int accumulate_dbias, int nwin, int win_per_img, int nwx, int Hp, int Wp, int ws,
+                                   int shift, int nH, int C, float scale, void* workspace, size_t workspace_bytes,
+                                   lc2is_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!qkv || !o || !dout || !lse || !bias || !dqkv) return LC2IS_ERR_NULL;
+  int rc = sw_check(nwin, win_per_img, nwx, Hp, Wp, ws, shift, nH, C);
+  if (rc) return rc;
+  if (ld < 3 * C || lddq < 3 * C || ld_o < C || lddo < C || ld % 8 || lddq % 8 || ld_o % 8 || lddo % 8) return LC2IS_ERR_SHAPE;
+  if (dbias && (!workspace || workspace_bytes < lc2is_swin_attn_bwd_workspace_bytes(nwin, ws, nH))) return LC2IS_ERR_WORKSPACE;
+  const int nchunk = sw_chunks(nwin, nH);
+  SwinAttnArgs a{};
+  a.qkv = (const bf16_t*)qkv; a.ld = ld; a.o = (const bf16_t*)o; a.ld_o = ld_o; a.dout = (const bf16_t*)dout; a.lddo = lddo;
+  a.lse = const_cast<float*>(lse); a.bias = bias; a.dqkv = (bf16_t*)dqkv; a.lddq = lddq;
+  a.dbias_part = dbias ? (float*)workspace : nullptr;
+  a.nwin = nwin; a.win_per_img = win_per_img; a.nwx = nwx; a.Hp = Hp; a.Wp = Wp; a.ws = ws; a.shift = shift; a.nH = nH;
+  a.C = C; a.scale = scale; a.chunk = (nwin + nchunk - 1) / nchunk;
+  const int lds = (4 * SW_MAXS * SW_D + 3 * SW_MAXS * (SW_MAXS + 1)) * (int)sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)swin_attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return LC2IS_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int nchunk_eff = (nwin + a.chunk - 1) / a.chunk;
+  hipLaunchKernelGGL(swin_attn_bwd_kernel, dim3(nchunk_eff * nH), dim3(64), lds, stream, a);
+  rc = lc2is_check_launch();
+  if (rc || !dbias) return rc;
+  const size_t n = (size_t)nH * ws * ws * ws * ws;
+  hipLaunchKernelGGL(swin_dbias_reduce_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, stream,
+                     (const float*)workspace, nchunk_eff, n, dbias, accumulate_dbias);
+  return lc2is_check_launch();
+}

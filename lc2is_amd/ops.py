@@ -14,6 +14,7 @@ import torch
 from . import _lib
 
 ACT_NONE, ACT_QUICK_GELU, ACT_RELU, ACT_DQUICK_GELU, ACT_DRELU, ACT_QUICK_GELU_GRAD, ACT_MUL_AUX = 0, 1, 2, 3, 4, 5, 6
+ACT_GELU_ERF, ACT_DGELU_ERF = 7, 8
 
 _P, _I, _F, _Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 _ARGTYPES = {
@@ -55,6 +56,11 @@ _ARGTYPES = {
     "lc2is_cols_ce": [_P, _P, _P, _P, _F, _I, _I, _I, _I, _P],
     "lc2is_npair": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "lc2is_miou_counts": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "lc2is_rows_gather": [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _P],
+    "lc2is_swin_attn_fwd": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P],
+    "lc2is_swin_attn_bwd_workspace_bytes": [_I, _I, _I],
+    "lc2is_swin_attn_bwd": [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F,
+                            _P, _Z, _P],
 }
 _bound = {}
 
@@ -65,6 +71,8 @@ def _fn(name: str):
         f = getattr(_lib.load(), name)
         if name in _ARGTYPES:
             f.argtypes = _ARGTYPES[name]
+        if name.endswith("_workspace_bytes"):
+            f.restype = C.c_size_t
         _bound[name] = f
     return f
 
@@ -586,3 +594,62 @@ def miou_counts(scores_hi, labels_lo, S: int):
     _lib.check(_fn("lc2is_miou_counts")(_ptr(scores_hi.contiguous()), _ptr(labels_lo.contiguous()), _ptr(counts), B, K, H,
                                         W, S, _stream()), "miou_counts")
     return counts
+
+
+# ---- Swin backbone ----------------------------------------------------------------------------------------------
+def rows_gather(src: torch.Tensor, index_map: torch.Tensor, *, out: torch.Tensor | None = None, out_dtype=None,
+                add: torch.Tensor | None = None, cols: int | None = None):
+    """out[r, :cols] = (map[r] >= 0 ? src[map[r], :cols] : 0) (+ add[r, :cols]).  src/out fp32 or bf16 2-D (row
+    strides allowed), map int32 [rows], add fp32."""
+    if src.dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError("lc2is_amd.rows_gather: src must be fp32 or bf16")
+    _chk(src, src.dtype, "src"); _chk(index_map, torch.int32, "map", 1); _chk(add, torch.float32, "add")
+    rows = index_map.numel()
+    cols = src.shape[1] if cols is None else cols
+    if out is None:
+        out = torch.empty((rows, cols), dtype=out_dtype or src.dtype, device=src.device)
+    if out.dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError("lc2is_amd.rows_gather: out must be fp32 or bf16")
+    _chk(out, out.dtype, "out")
+    if out.shape[0] != rows or out.shape[1] < cols or src.shape[1] < cols or (add is not None and add.shape[0] != rows):
+        raise RuntimeError("lc2is_amd.rows_gather: shape mismatch")
+    rc = _fn("lc2is_rows_gather")(_ptr(src), _ld(src), int(src.dtype == torch.bfloat16), _ptr(out), _ld(out),
+                                  int(out.dtype == torch.bfloat16), _ptr(index_map), _ptr(add), _ld(add), rows, cols,
+                                  _stream())
+    _lib.check(rc, f"rows_gather rows={rows} cols={cols}")
+    return out
+
+
+def swin_attn_fwd(qkv: torch.Tensor, bias: torch.Tensor, nwin: int, win_per_img: int, nwx: int, Hp: int, Wp: int,
+                  ws: int, shift: int, nH: int, scale: float, *, save_lse: bool = True):
+    """qkv bf16 [nwin*ws*ws, 3C]; bias fp32 [nH, S, S].  Returns (o bf16 [nwin*S, C], lse [nwin, nH, S])."""
+    _chk(qkv, torch.bfloat16, "qkv"); _dense(bias, torch.float32, "bias") if bias.dim() == 2 else _chk(bias, torch.float32, "bias", 3)
+    S, Cc = ws * ws, qkv.shape[1] // 3
+    if qkv.shape[0] != nwin * S or tuple(bias.shape) != (nH, S, S) or not bias.is_contiguous():
+        raise RuntimeError("lc2is_amd.swin_attn_fwd: shape mismatch")
+    o = torch.empty((nwin * S, Cc), dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty((nwin, nH, S), dtype=torch.float32, device=qkv.device)
+    rc = _fn("lc2is_swin_attn_fwd")(_ptr(qkv), _ld(qkv), _ptr(o), _ld(o), _ptr(lse), _ptr(bias), nwin, win_per_img, nwx,
+                                    Hp, Wp, ws, shift, nH, Cc, float(scale), _stream())
+    _lib.check(rc, f"swin_attn_fwd nwin={nwin} nH={nH} ws={ws}")
+    return o, (lse if save_lse else None)
+
+
+def swin_attn_bwd(qkv, o, do, lse, bias, nwin: int, win_per_img: int, nwx: int, Hp: int, Wp: int, ws: int, shift: int,
+                  nH: int, scale: float, *, dbias: torch.Tensor | None = None, accumulate_dbias: bool = False):
+    """Returns dqkv bf16 [nwin*S, 3C]; dbias fp32 [nH,S,S] is written (or accumulated) when given."""
+    for t, n in ((qkv, "qkv"), (o, "o"), (do, "do")):
+        _chk(t, torch.bfloat16, n)
+    _chk(lse, torch.float32, "lse", 3); _chk(bias, torch.float32, "bias", 3); _chk(dbias, torch.float32, "dbias", 3)
+    Cc = qkv.shape[1] // 3
+    dqkv = torch.empty_like(qkv)
+    ws_b = None
+    if dbias is not None:
+        nbytes = _fn("lc2is_swin_attn_bwd_workspace_bytes")(nwin, ws, nH)
+        ws_b = workspace(nbytes, qkv.device, "swin_attn")
+    rc = _fn("lc2is_swin_attn_bwd")(_ptr(qkv), _ld(qkv), _ptr(o), _ld(o), _ptr(do), _ld(do), _ptr(lse), _ptr(bias),
+                                    _ptr(dqkv), _ld(dqkv), _ptr(dbias), int(accumulate_dbias), nwin, win_per_img, nwx,
+                                    Hp, Wp, ws, shift, nH, Cc, float(scale), _ptr(ws_b),
+                                    0 if ws_b is None else ws_b.numel(), _stream())
+    _lib.check(rc, f"swin_attn_bwd nwin={nwin} nH={nH} ws={ws}")
+    return dqkv

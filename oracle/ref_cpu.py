@@ -518,3 +518,103 @@ def score_map_tail(visual_embeddings: Tensor, text_embeddings: Tensor, scale: in
     t = text_embeddings / text_embeddings.norm(dim=-1, keepdim=True).clamp_min(1e-12)
     score = torch.einsum("bhwc,bkc->bkhw", v, t)
     return upsample2d(score, scale_factor=scale, mode="bilinear")
+
+
+# ----------------------------------------------------------------------------------------------------------
+# Swin backbone: model/encoder.py:121-131 -> hf:models/swin/modeling_swin.py (transformers 5.15 key names)
+# ----------------------------------------------------------------------------------------------------------
+@dataclass
+class SwinCfg:
+    embed_dim: int = 96
+    depths: tuple = (2, 2, 18, 2)
+    num_heads: tuple = (3, 6, 12, 24)
+    window: int = 7
+    patch: int = 4
+    eps: float = 1e-5
+
+
+def swin_relative_position_index(ws: int) -> Tensor:
+    """SwinRelativePositionBias._create_relative_position_index (modeling_swin.py:350-365), flattened [ws^2 * ws^2]."""
+    coords = torch.stack(torch.meshgrid([torch.arange(ws), torch.arange(ws)], indexing="ij")).flatten(1)
+    rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += ws - 1
+    rel[:, :, 1] += ws - 1
+    rel[:, :, 0] *= 2 * ws - 1
+    return rel.sum(-1).view(-1)
+
+
+def swin_block(sd: dict, pre: str, x: Tensor, H: int, W: int, nH: int, ws: int, shift: int, eps: float) -> Tensor:
+    """SwinLayer.forward (modeling_swin.py:529-574), dropout / drop-path off."""
+    B, L, C = x.shape
+    if min(H, W) <= ws:
+        raise NotImplementedError("oracle swin_block: grids no larger than the window are outside the path (512^2 input)")
+    g = lambda k: sd[pre + k]  # noqa: E731
+    h = layer_norm(x, g("layernorm_before.weight"), g("layernorm_before.bias"), eps).view(B, H, W, C)
+    pad_r, pad_b = (ws - W % ws) % ws, (ws - H % ws) % ws
+    h = torch.nn.functional.pad(h, (0, 0, 0, pad_r, 0, pad_b))
+    Hp, Wp = H + pad_b, W + pad_r
+    if shift > 0:
+        h = torch.roll(h, shifts=(-shift, -shift), dims=(1, 2))
+    win = h.view(B, Hp // ws, ws, Wp // ws, ws, C).transpose(2, 3).reshape(-1, ws * ws, C)
+    S, D = ws * ws, C // nH
+    q = linear(win, g("attention.q_proj.weight"), g("attention.q_proj.bias")).view(-1, S, nH, D).transpose(1, 2)
+    k = linear(win, g("attention.k_proj.weight"), g("attention.k_proj.bias")).view(-1, S, nH, D).transpose(1, 2)
+    v = linear(win, g("attention.v_proj.weight"), g("attention.v_proj.bias")).view(-1, S, nH, D).transpose(1, 2)
+    table = g("attention.relative_position_bias.relative_position_bias_table")          # [(2ws-1)^2, nH]
+    bias = table[swin_relative_position_index(ws)].view(S, S, nH).permute(2, 0, 1)        # [nH, S, S]
+    logits = (q @ k.transpose(-1, -2)) * (D ** -0.5) + bias[None]
+    if shift > 0:                                                                        # get_attn_mask (:584-607)
+        hr = (torch.arange(Hp) >= Hp - ws).long() + (torch.arange(Hp) >= Hp - shift).long()
+        wr = (torch.arange(Wp) >= Wp - ws).long() + (torch.arange(Wp) >= Wp - shift).long()
+        img = (hr[:, None] * 3 + wr[None, :]).to(x.dtype)
+        mw = img.view(Hp // ws, ws, Wp // ws, ws).transpose(1, 2).reshape(-1, S)
+        am = mw[:, None, :] - mw[:, :, None]
+        am = torch.where(am != 0, torch.full_like(am, -100.0), torch.zeros_like(am))     # [nW, S, S]
+        nW = am.shape[0]
+        logits = (logits.view(B, nW, nH, S, S) + am[None, :, None]).view(-1, nH, S, S)
+    o = (torch.softmax(logits, dim=-1) @ v).transpose(1, 2).reshape(-1, S, C)
+    o = linear(o, g("attention.o_proj.weight"), g("attention.o_proj.bias"))
+    o = o.view(B, Hp // ws, Wp // ws, ws, ws, C).transpose(2, 3).reshape(B, Hp, Wp, C)
+    if shift > 0:
+        o = torch.roll(o, shifts=(shift, shift), dims=(1, 2))
+    x = x + o[:, :H, :W, :].reshape(B, H * W, C)
+    h2 = layer_norm(x, g("layernorm_after.weight"), g("layernorm_after.bias"), eps)
+    h2 = linear(h2, g("mlp.fc1.weight"), g("mlp.fc1.bias"))
+    h2 = 0.5 * h2 * (1.0 + torch.erf(h2 * 0.7071067811865476))                          # hf:activations "gelu" (exact)
+    return x + linear(h2, g("mlp.fc2.weight"), g("mlp.fc2.bias"))
+
+
+def swin_patch_merging(sd: dict, pre: str, x: Tensor, H: int, W: int, eps: float = 1e-5) -> Tensor:
+    """SwinPatchMerging.forward (modeling_swin.py:309-326): pad to even, concat 2x2 neighbours (col-major order),
+    LayerNorm(4C), Linear(4C -> 2C, no bias)."""
+    B, L, C = x.shape
+    f = x.view(B, H, W, C)
+    if H % 2 or W % 2:
+        f = torch.nn.functional.pad(f, (0, 0, 0, W % 2, 0, H % 2))
+    f = torch.cat([f[:, r::2, c::2, :] for c in range(2) for r in range(2)], dim=-1).reshape(B, -1, 4 * C)
+    f = layer_norm(f, sd[pre + "norm.weight"], sd[pre + "norm.bias"], eps)
+    return linear(f, sd[pre + "reduction.weight"], None)
+
+
+def swin_hidden_states(sd: dict, pre: str, pixel_values: Tensor, cfg: SwinCfg, n_out: int = 4) -> list:
+    """SwinTransformer.forward (model/encoder.py:129-131): SwinModel(..., output_hidden_states=True).hidden_states[:4]
+    = (patch embedding output, stage 1/2/3 outputs AFTER their patch merging); `pre` is the reference's attribute path
+    ("encoder.").  Stage 4 and the final layernorm never reach those four tensors and are not evaluated."""
+    B, _, Hi, Wi = pixel_values.shape
+    p = cfg.patch
+    if Hi % p or Wi % p:
+        pixel_values = torch.nn.functional.pad(pixel_values, (0, (p - Wi % p) % p, 0, (p - Hi % p) % p))
+    x = torch.nn.functional.conv2d(pixel_values, sd[pre + "embeddings.patch_embeddings.projection.weight"],
+                                   sd[pre + "embeddings.patch_embeddings.projection.bias"], stride=p)
+    H, W = x.shape[2], x.shape[3]
+    x = x.flatten(2).transpose(1, 2)
+    x = layer_norm(x, sd[pre + "embeddings.norm.weight"], sd[pre + "embeddings.norm.bias"], cfg.eps)
+    outs = [x]
+    for si in range(n_out - 1):
+        for bi in range(cfg.depths[si]):
+            x = swin_block(sd, f"{pre}encoder.layers.{si}.blocks.{bi}.", x, H, W, cfg.num_heads[si], cfg.window,
+                           0 if bi % 2 == 0 else cfg.window // 2, cfg.eps)
+        x = swin_patch_merging(sd, f"{pre}encoder.layers.{si}.downsample.", x, H, W, cfg.eps)
+        H, W = (H + 1) // 2, (W + 1) // 2
+        outs.append(x)
+    return outs

@@ -301,6 +301,46 @@ def make_ftn(R):
     print("ftn:", tuple(out.shape), "params without grad:", len(fx["no_grad"]), "fixture rows:", fx["out"].shape[1])
 
 
+def make_swin(R):
+    """SwinTransformer.forward (model/encoder.py:121-131) with a config-built tiny SwinModel (hub constructor cannot run
+    offline): embed 32, heads [1,2,4,8] (head_dim 32 like every Swin), window 5 on a 44x44 grid so that padding to the
+    window (44->45, 22->25, 11->15), the cyclic shift + region mask, and the odd-size patch merging (11->12) all occur.
+    Forward + backward through hidden_states[:4]."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    from golden_util import make_weights
+    from transformers import SwinConfig, SwinModel
+    cfg = SwinConfig(image_size=176, patch_size=4, embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], window_size=5,
+                     drop_path_rate=0.0)
+    cfg._attn_implementation = "eager"
+    m = _bare(R["renc"].SwinTransformer)
+    m.encoder = SwinModel(cfg)
+    m.train()
+    params = dict(m.named_parameters())
+    shapes = {k: list(v.shape) for k, v in params.items()}
+    w = make_weights(shapes, 61)
+    with torch.no_grad():
+        for k, p in params.items():
+            p.copy_(w[k])
+    g = torch.Generator().manual_seed(62)
+    x = torch.randn(2, 3, 176, 176, generator=g)
+    outs = m(x)                                   # the reference's own forward
+    assert len(outs) == 4
+    douts = [torch.randn(o.shape, generator=g) * 0.2 for o in outs]
+    sum((o * d).sum() for o, d in zip(outs, douts)).backward()
+    names = list(params)
+    keep = [k for k in names if params[k].grad is not None and
+            (k.endswith("relative_position_bias_table") or "norm" in k or k.endswith("bias") or ".blocks.0.attention.q_proj.weight" in k
+             or k.endswith("reduction.weight") or k.endswith("projection.weight") or ".blocks.1.mlp.fc1.weight" in k)]
+    fx = dict(shapes={k: torch.tensor(v) for k, v in shapes.items()}, wseed=torch.tensor(61), pixel_values=x,
+              outs=[o.detach() for o in outs], douts=douts,
+              grad_stats={k: (torch.stack([p.grad.sum(), p.grad.abs().sum()]) if p.grad is not None else torch.zeros(2))
+                          for k, p in params.items()},
+              no_grad=torch.tensor([i for i, k in enumerate(names) if params[k].grad is None]),
+              grad_full={k: params[k].grad.clone() for k in keep})
+    torch.save(fx, OUT / "swin_tiny.pt")
+    print("swin:", [tuple(o.shape) for o in outs], "params without grad:", len(fx["no_grad"]), "full grads:", len(keep))
+
+
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
     R = _ref_imports()
@@ -310,11 +350,15 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "ftn":
         make_ftn(R)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "swin":
+        make_swin(R)
+        return
     make_base_tiny(R)
     make_decoder_d96(R)
     make_ops(R)
     make_hier(R)
     make_ftn(R)
+    make_swin(R)
     # the reference's only data fixture on this path — copied as-is
     protos = torch.load(REF / "model" / "ade20k_prototypes.pt", weights_only=True)
     torch.save(protos.clone(), OUT / "ade20k_prototypes.pt")
