@@ -621,13 +621,16 @@ def rows_gather(src: torch.Tensor, index_map: torch.Tensor, *, out: torch.Tensor
 
 
 def swin_attn_fwd(qkv: torch.Tensor, bias: torch.Tensor, nwin: int, win_per_img: int, nwx: int, Hp: int, Wp: int,
-                  ws: int, shift: int, nH: int, scale: float, *, save_lse: bool = True):
+                  ws: int, shift: int, nH: int, scale: float, *, save_lse: bool = True, out: torch.Tensor | None = None):
     """qkv bf16 [nwin*ws*ws, 3C]; bias fp32 [nH, S, S].  Returns (o bf16 [nwin*S, C], lse [nwin, nH, S])."""
     _chk(qkv, torch.bfloat16, "qkv"); _dense(bias, torch.float32, "bias") if bias.dim() == 2 else _chk(bias, torch.float32, "bias", 3)
     S, Cc = ws * ws, qkv.shape[1] // 3
     if qkv.shape[0] != nwin * S or tuple(bias.shape) != (nH, S, S) or not bias.is_contiguous():
         raise RuntimeError("lc2is_amd.swin_attn_fwd: shape mismatch")
-    o = torch.empty((nwin * S, Cc), dtype=torch.bfloat16, device=qkv.device)
+    o = out if out is not None else torch.empty((nwin * S, Cc), dtype=torch.bfloat16, device=qkv.device)
+    _chk(o, torch.bfloat16, "out")
+    if tuple(o.shape) != (nwin * S, Cc):
+        raise RuntimeError("lc2is_amd.swin_attn_fwd: out shape mismatch")
     lse = torch.empty((nwin, nH, S), dtype=torch.float32, device=qkv.device)
     rc = _fn("lc2is_swin_attn_fwd")(_ptr(qkv), _ld(qkv), _ptr(o), _ld(o), _ptr(lse), _ptr(bias), nwin, win_per_img, nwx,
                                     Hp, Wp, ws, shift, nH, Cc, float(scale), _stream())
@@ -636,13 +639,18 @@ def swin_attn_fwd(qkv: torch.Tensor, bias: torch.Tensor, nwin: int, win_per_img:
 
 
 def swin_attn_bwd(qkv, o, do, lse, bias, nwin: int, win_per_img: int, nwx: int, Hp: int, Wp: int, ws: int, shift: int,
-                  nH: int, scale: float, *, dbias: torch.Tensor | None = None, accumulate_dbias: bool = False):
+                  nH: int, scale: float, *, dbias: torch.Tensor | None = None, accumulate_dbias: bool = False,
+                  dqkv: torch.Tensor | None = None):
     """Returns dqkv bf16 [nwin*S, 3C]; dbias fp32 [nH,S,S] is written (or accumulated) when given."""
     for t, n in ((qkv, "qkv"), (o, "o"), (do, "do")):
         _chk(t, torch.bfloat16, n)
     _chk(lse, torch.float32, "lse", 3); _chk(bias, torch.float32, "bias", 3); _chk(dbias, torch.float32, "dbias", 3)
     Cc = qkv.shape[1] // 3
-    dqkv = torch.empty_like(qkv)
+    if dqkv is None:
+        dqkv = torch.empty(qkv.shape, dtype=torch.bfloat16, device=qkv.device)
+    _chk(dqkv, torch.bfloat16, "dqkv")
+    if dqkv.shape != qkv.shape:
+        raise RuntimeError("lc2is_amd.swin_attn_bwd: dqkv shape mismatch")
     ws_b = None
     if dbias is not None:
         nbytes = _fn("lc2is_swin_attn_bwd_workspace_bytes")(nwin, ws, nH)
