@@ -161,118 +161,139 @@ __global__ __launch_bounds__(256) void swin_attn_fwd_kernel(SwinAttnArgs a) {
   }
 }
 
-// backward: one wave per block; block (h, chunk) walks the windows of its chunk in order
+// backward: one wave per block; block (h, chunk) walks the windows of its chunk in order.
+// LDS per block (22.5 KiB at S = 49, so seven blocks share a CU): two [S][32] fp32 tiles — K,V while the lanes are query
+// rows (pass A: dQ), then overwritten by Q,dO while the lanes are key rows (pass B: dK, dV, with the logits recomputed
+// rather than a [S][S] P / dS matrix kept) — plus the [S][S] bias-gradient accumulator and the per-row lse / delta.
 __global__ __launch_bounds__(64) void swin_attn_bwd_kernel(SwinAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x;
   const int S = a.ws * a.ws;
   const int h = blockIdx.x % a.nH, chunk = blockIdx.x / a.nH;
-  float* Qs = (float*)smem;                    // [S][32] each
-  float* Ks = Qs + SW_MAXS * SW_D;
-  float* Vs = Ks + SW_MAXS * SW_D;
-  float* Ds = Vs + SW_MAXS * SW_D;             // dO
-  float* Pm = Ds + SW_MAXS * SW_D;             // [S][S+1]
-  float* Sm = Pm + SW_MAXS * (SW_MAXS + 1);    // dS
-  float* Acc = Sm + SW_MAXS * (SW_MAXS + 1);   // [S][S+1] bias-gradient accumulator of this block
-  const int PS = S + 1;
+  float* T0 = (float*)smem;                    // [S][32]: K, then Q
+  float* T1 = T0 + S * SW_D;                   // [S][32]: V, then dO
+  float* Acc = T1 + S * SW_D;                  // [S][S]
+  float* Ls = Acc + S * S;                     // [S] lse
+  float* Dl = Ls + S;                          // [S] delta = dO . O
   const bool act = lane < S;
-  for (int j = 0; j < S; ++j)
-    if (act) Acc[lane * PS + j] = 0.f;
+  for (int idx = lane; idx < S * S; idx += 64) Acc[idx] = 0.f;
   const int w_begin = chunk * a.chunk;
   int w_end = w_begin + a.chunk;
   if (w_end > a.nwin) w_end = a.nwin;
-  const float* brow = a.bias + ((size_t)h * S + (act ? lane : 0)) * S;
+  const int li = act ? lane : 0;
+  const int iy = li / a.ws, ix = li % a.ws;
   for (int win = w_begin; win < w_end; ++win) {
-    const size_t row = (size_t)win * S + (act ? lane : 0);
-    float q[SW_D], dO[SW_D], kv[SW_D];
-    float delta = 0.f;
+    const size_t row = (size_t)win * S + li;
+    float q[SW_D], dO[SW_D], kr[SW_D], vr[SW_D];
     sw_load_row(a.qkv + row * a.ld + h * SW_D, q);
     sw_load_row(a.dout + row * a.lddo + h * SW_D, dO);
+    sw_load_row(a.qkv + row * a.ld + a.C + h * SW_D, kr);
+    sw_load_row(a.qkv + row * a.ld + 2 * a.C + h * SW_D, vr);
+    float delta = 0.f;
     {
       float ov[SW_D];
       sw_load_row(a.o + row * a.ld_o + h * SW_D, ov);
 #pragma unroll
       for (int d = 0; d < SW_D; ++d) delta += dO[d] * ov[d];
     }
-    SW_LDS_SYNC();   // previous window's pass B reads are done before its tiles are overwritten
-    sw_load_row(a.qkv + row * a.ld + a.C + h * SW_D, kv);
+    const float lse = a.lse[((size_t)win * a.nH + h) * S + li];
+    SW_LDS_SYNC();   // the previous window's pass B has finished with the tiles
     if (act) {
 #pragma unroll
-      for (int d = 0; d < SW_D; ++d) { Qs[lane * SW_D + d] = q[d]; Ks[lane * SW_D + d] = kv[d]; Ds[lane * SW_D + d] = dO[d]; }
-    }
-    sw_load_row(a.qkv + row * a.ld + 2 * a.C + h * SW_D, kv);
-    if (act) {
-#pragma unroll
-      for (int d = 0; d < SW_D; ++d) Vs[lane * SW_D + d] = kv[d];
+      for (int d = 0; d < SW_D; ++d) { T0[lane * SW_D + d] = kr[d]; T1[lane * SW_D + d] = vr[d]; }
+      Ls[lane] = lse;
+      Dl[lane] = delta;
     }
     SW_LDS_SYNC();
-    const float lse = act ? a.lse[((size_t)win * a.nH + h) * S + lane] : 0.f;
     const int widx = win % a.win_per_img, wy = widx / a.nwx, wx = widx % a.nwx;
-    const int iy = (act ? lane : 0) / a.ws, ix = (act ? lane : 0) % a.ws;
     const int rid = a.shift > 0 ? sw_region(wy * a.ws + iy, a.Hp, a.ws, a.shift) * 3 + sw_region(wx * a.ws + ix, a.Wp, a.ws, a.shift) : 0;
-    // ---- pass A: lane = query row ----
-    float dq[SW_D];
+    // ---- pass A: lane = query row i ----
+    {
+      const float* brow = a.bias + ((size_t)h * S + li) * S;
+      float dq[SW_D];
 #pragma unroll
-    for (int d = 0; d < SW_D; ++d) dq[d] = 0.f;
-    for (int j = 0; j < S; ++j) {
-      const float* kj = Ks + j * SW_D;
-      const float* vj = Vs + j * SW_D;
-      float s = 0.f, dp = 0.f;
+      for (int d = 0; d < SW_D; ++d) dq[d] = 0.f;
+      for (int j = 0; j < S; ++j) {
+        const float* kj = T0 + j * SW_D;
+        const float* vj = T1 + j * SW_D;
+        float s = 0.f, dp = 0.f;
 #pragma unroll
-      for (int d = 0; d < SW_D; ++d) { s += q[d] * kj[d]; dp += dO[d] * vj[d]; }
-      s = s * a.scale + brow[j];
-      if (a.shift > 0) {
-        const int rj = sw_region(wy * a.ws + j / a.ws, a.Hp, a.ws, a.shift) * 3 + sw_region(wx * a.ws + j % a.ws, a.Wp, a.ws, a.shift);
-        if (rj != rid) s += -100.0f;
+        for (int d = 0; d < SW_D; ++d) { s += q[d] * kj[d]; dp += dO[d] * vj[d]; }
+        s = s * a.scale + brow[j];
+        if (a.shift > 0) {
+          const int rj = sw_region(wy * a.ws + j / a.ws, a.Hp, a.ws, a.shift) * 3 + sw_region(wx * a.ws + j % a.ws, a.Wp, a.ws, a.shift);
+          if (rj != rid) s += -100.0f;
+        }
+        const float dss = __expf(s - lse) * (dp - delta) * a.scale;
+#pragma unroll
+        for (int d = 0; d < SW_D; ++d) dq[d] += dss * kj[d];
       }
-      const float p = __expf(s - lse);
-      const float ds = p * (dp - delta);
-      if (act) {
-        Pm[lane * PS + j] = p;
-        Sm[lane * PS + j] = ds;
-        Acc[lane * PS + j] += ds;
-      }
-      const float dss = ds * a.scale;
-#pragma unroll
-      for (int d = 0; d < SW_D; ++d) dq[d] += dss * kj[d];
+      if (act) sw_store_row(a.dqkv + row * a.lddq + h * SW_D, dq);
     }
-    if (act) sw_store_row(a.dqkv + row * a.lddq + h * SW_D, dq);
-    SW_LDS_SYNC();
-    // ---- pass B: lane = key row ----
-    float dk[SW_D], dv[SW_D];
-#pragma unroll
-    for (int d = 0; d < SW_D; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
-    for (int i = 0; i < S; ++i) {
-      const float p = act ? Pm[i * PS + lane] : 0.f;
-      const float dss = (act ? Sm[i * PS + lane] : 0.f) * a.scale;
-      const float* qi = Qs + i * SW_D;
-      const float* di = Ds + i * SW_D;
-#pragma unroll
-      for (int d = 0; d < SW_D; ++d) { dk[d] += dss * qi[d]; dv[d] += p * di[d]; }
-    }
+    SW_LDS_SYNC();   // every lane is done reading K, V
     if (act) {
-      sw_store_row(a.dqkv + row * a.lddq + a.C + h * SW_D, dk);
-      sw_store_row(a.dqkv + row * a.lddq + 2 * a.C + h * SW_D, dv);
+#pragma unroll
+      for (int d = 0; d < SW_D; ++d) { T0[lane * SW_D + d] = q[d]; T1[lane * SW_D + d] = dO[d]; }
+    }
+    SW_LDS_SYNC();
+    // ---- pass B: lane = key row j (own k, v rows are still in registers) ----
+    {
+      float dk[SW_D], dv[SW_D];
+#pragma unroll
+      for (int d = 0; d < SW_D; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+      const float* bcol = a.bias + (size_t)h * S * S + li;
+      for (int i = 0; i < S; ++i) {
+        const float* qi = T0 + i * SW_D;
+        const float* di = T1 + i * SW_D;
+        float s = 0.f, dp = 0.f;
+#pragma unroll
+        for (int d = 0; d < SW_D; ++d) { s += qi[d] * kr[d]; dp += di[d] * vr[d]; }
+        s = s * a.scale + bcol[(size_t)i * S];
+        if (a.shift > 0) {
+          const int ri = sw_region(wy * a.ws + i / a.ws, a.Hp, a.ws, a.shift) * 3 + sw_region(wx * a.ws + i % a.ws, a.Wp, a.ws, a.shift);
+          if (ri != rid) s += -100.0f;   // rid: region of this lane's own token (here the key)
+        }
+        const float p = __expf(s - Ls[i]);
+        const float ds = p * (dp - Dl[i]);
+        if (act) Acc[i * S + lane] += ds;
+        const float dss = ds * a.scale;
+#pragma unroll
+        for (int d = 0; d < SW_D; ++d) { dk[d] += dss * qi[d]; dv[d] += p * di[d]; }
+      }
+      if (act) {
+        sw_store_row(a.dqkv + row * a.lddq + a.C + h * SW_D, dk);
+        sw_store_row(a.dqkv + row * a.lddq + 2 * a.C + h * SW_D, dv);
+      }
     }
   }
   SW_LDS_SYNC();
-  if (a.dbias_part && act) {
-    float* dst = a.dbias_part + (((size_t)chunk * a.nH + h) * S + lane) * S;
-    for (int j = 0; j < S; ++j) dst[j] = Acc[lane * PS + j];
+  if (a.dbias_part) {
+    float* dst = a.dbias_part + ((size_t)chunk * a.nH + h) * S * S;
+    for (int idx = lane; idx < S * S; idx += 64) dst[idx] = Acc[idx];
   }
 }
 
+// sum of the per-chunk partials in chunk order: 32 columns x 8 chunk groups per block, groups combined in a fixed order
 __global__ __launch_bounds__(256) void swin_dbias_reduce_kernel(const float* __restrict__ part, int nchunk, size_t n,
                                                                  float* out, int accumulate) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+  __shared__ float red[8][32];
+  const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const size_t i = (size_t)blockIdx.x * 32 + col;
   float s = 0.f;
-  for (int c = 0; c < nchunk; ++c) s += part[(size_t)c * n + i];
-  out[i] = accumulate ? out[i] + s : s;
+  if (i < n)
+    for (int c = grp; c < nchunk; c += 8) s += part[(size_t)c * n + i];
+  red[grp][col] = s;
+  __syncthreads();
+  if (grp == 0 && i < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) t += red[g][col];
+    out[i] = accumulate ? out[i] + t : t;
+  }
 }
 
 inline int sw_chunks(int nwin, int nH) {
-  int nchunk = 2048 / (nH > 0 ? nH : 1);   // ~2048 single-wave blocks
+  int nchunk = 1792 / (nH > 0 ? nH : 1);   // ~7 single-wave blocks per CU (LDS-limited residency)
   if (nchunk < 1) nchunk = 1;
   if (nchunk > nwin) nchunk = nwin;
   return nchunk;
@@ -354,7 +375,8 @@ extern "C" int lc2is_swin_attn_bwd(const void* qkv, int ld, const void* o, int l
   a.dbias_part = dbias ? (float*)workspace : nullptr;
   a.nwin = nwin; a.win_per_img = win_per_img; a.nwx = nwx; a.Hp = Hp; a.Wp = Wp; a.ws = ws; a.shift = shift; a.nH = nH;
   a.C = C; a.scale = scale; a.chunk = (nwin + nchunk - 1) / nchunk;
-  const int lds = (4 * SW_MAXS * SW_D + 3 * SW_MAXS * (SW_MAXS + 1)) * (int)sizeof(float);
+  const int S_ = ws * ws;
+  const int lds = (2 * S_ * SW_D + S_ * S_ + 2 * S_) * (int)sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)swin_attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
@@ -366,7 +388,7 @@ extern "C" int lc2is_swin_attn_bwd(const void* qkv, int ld, const void* o, int l
   rc = lc2is_check_launch();
   if (rc || !dbias) return rc;
   const size_t n = (size_t)nH * ws * ws * ws * ws;
-  hipLaunchKernelGGL(swin_dbias_reduce_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, stream,
+  hipLaunchKernelGGL(swin_dbias_reduce_kernel, dim3((int)((n + 31) / 32)), dim3(256), 0, stream,
                      (const float*)workspace, nchunk_eff, n, dbias, accumulate_dbias);
   return lc2is_check_launch();
 }

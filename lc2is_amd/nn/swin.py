@@ -305,12 +305,15 @@ class SwinTransformer(HipModule):
         if x16p.shape[1] == C_in:
             linear_bwd_params(dy16, x16p, weight, bias)
             return
+        gb, accb = vec_grad(bias)
         if weight.requires_grad:
             gw, acc = grad_buf(weight)
-            tmp = ops.gemm_tn(dy16, x16p)
+            tmp_b = torch.empty_like(gb) if gb is not None else None
+            tmp = ops.gemm_tn(dy16, x16p, db=tmp_b)                     # bias gradient rides on the same launch
             gw.add_(tmp[:, :C_in]) if acc else gw.copy_(tmp[:, :C_in])
-        if bias is not None and bias.requires_grad:
-            gb, accb = grad_buf(bias)
+            if gb is not None:
+                gb.add_(tmp_b) if accb else gb.copy_(tmp_b)
+        elif gb is not None:
             ops.colsum(dy16, gb, accumulate=accb)
 
     # ---- one block ------------------------------------------------------------------------------------------------------

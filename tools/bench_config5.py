@@ -23,27 +23,32 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--classes", type=int, default=150)
+    ap.add_argument("--swin", action="store_true", help="end to end: Swin-small backbone (drop_path 0) produces the stage "
+                    "tensors from 512x512 pixels instead of the synthetic ones")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     B, K = args.batch, args.classes
     torch.manual_seed(5)
     dec = N.HierarchicalCrossA([96, 192, 384, 768], [1, 1, 1], 512, nhead=8, dropout=0).to(dev).train()
     tail = N.ScoreMapTail(4)
-    arena = ParamArena(dec)
+    swin = N.SwinTransformer(N.SWIN_S, drop_path_rate=0.0).to(dev).train() if args.swin else None
+    model = torch.nn.ModuleList([dec] + ([swin] if swin is not None else []))
+    arena = ParamArena(model)
     g = torch.Generator().manual_seed(5)
     visual = [torch.randn(B, p, c, generator=g).to(dev) for p, c in zip((16384, 4096, 1024, 256), (96, 192, 384, 768))]
     text = torch.randn(B, K, 512, generator=g).to(dev).requires_grad_(True)
     labels = torch.randint(0, K, (B, 512, 512), generator=g).to(dev)
+    pixels = torch.randn(B, 3, 512, 512, generator=g).to(dev) if args.swin else None
 
     def step():
         arena.zero_grad(set_to_none=True)
         text.grad = None
-        emb = dec(visual, text)
+        emb = dec(list(swin(pixels)) if swin is not None else visual, text)
         loss = tail.loss(emb, text, labels)
         loss.backward()
         arena.finalize_grads()
         ops.sgd_step(arena.flat, arena.grad, None, 1e-5)
-        for m in dec.modules():
+        for m in model.modules():
             if isinstance(m, N.HipModule):
                 m.invalidate_shadows()
         return loss
