@@ -232,6 +232,21 @@ int lc2is_swin_attn_bwd(const void* qkv, int ld, const void* o, int ld_o, const 
                         int win_per_img, int nwx, int Hp, int Wp, int ws, int shift, int nH, int C, float scale,
                         void* workspace, size_t workspace_bytes, lc2is_stream_t stream);
 
+/* ---- preprocessing in front of the path (evaluate.py:58-61, data/collator.py:82-91; Pillow inside transformers'
+ * CLIPFeatureExtractor) — byte / integer work, bit-exact against Pillow --------------------------------------------
+ * resample_u8: one separable 8-bit pass of PIL's ImagingResample over an HWC uint8 image along `axis` (1 = width,
+ *   0 = height): out = clip8((1<<21 + sum_t in[first+t] * kk[o][t]) >> 22) with bounds[o] = (first, count) and the
+ *   22-bit fixed-point coefficients built on the host as Resample.c precompute_coeffs / normalize_coeffs_8bpc do.
+ * gather2d_u8: dst[y][x][c] = src[yi[y]][xi[x]][c] (nearest resize, Geometry.c ImagingScaleAffine index vectors).
+ * crop_lut: S x S crop at (top,left) + 256-entry lookup: uint8 HWC -> float32 CHW via lut_f32[C][256] (x/255 and
+ *   (x-mean)/std folded in with the reference's float ops) and / or channel 0 -> int64 via lut_i64[256] (labels). */
+int lc2is_resample_u8(const void* src_u8, int H, int W, int C, void* dst_u8, int out_size, int axis, const int* bounds,
+                      const int* kk, int ksize, lc2is_stream_t stream);
+int lc2is_gather2d_u8(const void* src_u8, int H, int W, int C, void* dst_u8, int out_h, int out_w, const int* yi,
+                      const int* xi, lc2is_stream_t stream);
+int lc2is_crop_lut(const void* src_u8, int H, int W, int C, int top, int left, int S, const float* lut_f32,
+                   float* dst_f32, const int64_t* lut_i64, int64_t* dst_i64, lc2is_stream_t stream);
+
 /* ---- remaining losses (model/loss.py) and the parity metric (metrics.py) on channels-last scores ----------
  * rows_ce: softmax-CE over the K contiguous classes of each of M rows: loss_sum[0] += sum of per-row losses,
  *   lse[M] (optional), dx (optional) (+)= grad_scale * (softmax - onehot).  ContrastiveLoss.loss_visual

@@ -57,6 +57,9 @@ _ARGTYPES = {
     "lc2is_npair": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "lc2is_miou_counts": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "lc2is_rows_gather": [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _P],
+    "lc2is_resample_u8": [_P, _I, _I, _I, _P, _I, _I, _P, _P, _I, _P],
+    "lc2is_gather2d_u8": [_P, _I, _I, _I, _P, _I, _I, _P, _P, _P],
+    "lc2is_crop_lut": [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "lc2is_swin_attn_fwd": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P],
     "lc2is_swin_attn_bwd_workspace_bytes": [_I, _I, _I],
     "lc2is_swin_attn_bwd": [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F,
@@ -661,3 +664,53 @@ def swin_attn_bwd(qkv, o, do, lse, bias, nwin: int, win_per_img: int, nwx: int, 
                                     0 if ws_b is None else ws_b.numel(), _stream())
     _lib.check(rc, f"swin_attn_bwd nwin={nwin} nH={nH} ws={ws}")
     return dqkv
+
+
+# ---- preprocessing (uint8 images) ---------------------------------------------------------------------------------
+def _u8(t, name):
+    if not t.is_cuda or t.dtype != torch.uint8 or t.dim() != 3 or not t.is_contiguous():
+        raise RuntimeError(f"lc2is_amd: {name} must be a contiguous uint8 HWC tensor on a HIP device")
+
+
+def resample_u8(src: torch.Tensor, out_size: int, axis: int, bounds: torch.Tensor, kk: torch.Tensor):
+    """One separable 8-bit Pillow resampling pass over an HWC uint8 image (axis 1 = width, 0 = height)."""
+    _u8(src, "src"); _chk(bounds, torch.int32, "bounds"); _chk(kk, torch.int32, "kk")
+    H, W, Cc = src.shape
+    if tuple(bounds.shape) != (out_size, 2) or kk.shape[0] != out_size or not (bounds.is_contiguous() and kk.is_contiguous()):
+        raise RuntimeError("lc2is_amd.resample_u8: coefficient tables do not match out_size")
+    out = torch.empty((out_size, W, Cc) if axis == 0 else (H, out_size, Cc), dtype=torch.uint8, device=src.device)
+    rc = _fn("lc2is_resample_u8")(_ptr(src), H, W, Cc, _ptr(out), out_size, axis, _ptr(bounds), _ptr(kk), kk.shape[1], _stream())
+    _lib.check(rc, f"resample_u8 {H}x{W}x{Cc} -> {out_size} axis {axis}")
+    return out
+
+
+def gather2d_u8(src: torch.Tensor, yi: torch.Tensor, xi: torch.Tensor):
+    _u8(src, "src"); _chk(yi, torch.int32, "yi", 1); _chk(xi, torch.int32, "xi", 1)
+    H, W, Cc = src.shape
+    out = torch.empty((yi.numel(), xi.numel(), Cc), dtype=torch.uint8, device=src.device)
+    rc = _fn("lc2is_gather2d_u8")(_ptr(src), H, W, Cc, _ptr(out), yi.numel(), xi.numel(), _ptr(yi), _ptr(xi), _stream())
+    _lib.check(rc, "gather2d_u8")
+    return out
+
+
+def crop_lut(src: torch.Tensor, top: int, left: int, S: int, *, lut_f32: torch.Tensor | None = None,
+             out_f32: torch.Tensor | None = None, lut_i64: torch.Tensor | None = None, out_i64: torch.Tensor | None = None):
+    """S x S crop + lookup: float32 CHW pixel values (lut_f32 [C,256]) and / or int64 label ids of channel 0 (lut_i64 [256])."""
+    _u8(src, "src")
+    H, W, Cc = src.shape
+    if lut_f32 is not None:
+        _chk(lut_f32, torch.float32, "lut_f32")
+        if tuple(lut_f32.shape) != (Cc, 256) or not lut_f32.is_contiguous():
+            raise RuntimeError("lc2is_amd.crop_lut: lut_f32 must be [C,256]")
+        out_f32 = out_f32 if out_f32 is not None else torch.empty((Cc, S, S), dtype=torch.float32, device=src.device)
+        if tuple(out_f32.shape) != (Cc, S, S) or not out_f32.is_contiguous() or out_f32.dtype != torch.float32:
+            raise RuntimeError("lc2is_amd.crop_lut: out_f32 must be contiguous float32 [C,S,S]")
+    if lut_i64 is not None:
+        _chk(lut_i64, torch.int64, "lut_i64", 1)
+        out_i64 = out_i64 if out_i64 is not None else torch.empty((S, S), dtype=torch.int64, device=src.device)
+        if tuple(out_i64.shape) != (S, S) or not out_i64.is_contiguous() or out_i64.dtype != torch.int64:
+            raise RuntimeError("lc2is_amd.crop_lut: out_i64 must be contiguous int64 [S,S]")
+    rc = _fn("lc2is_crop_lut")(_ptr(src), H, W, Cc, top, left, S, _ptr(lut_f32), _ptr(out_f32 if lut_f32 is not None else None),
+                               _ptr(lut_i64), _ptr(out_i64 if lut_i64 is not None else None), _stream())
+    _lib.check(rc, f"crop_lut {H}x{W} crop {S}@({top},{left})")
+    return out_f32, out_i64

@@ -30,6 +30,44 @@ __global__ __launch_bounds__(512) void k(unsigned short* out, int M, int N) {
     if (NT_) __builtin_nontemporal_store(v, p); else *p = v;
   }
 }
+// fp32 read-modify-write of a [M,N] fp32 matrix in the GEMM epilogue's direct footprint: wave instruction = 16 rows x 64 B
+// (mode 0) vs 4 rows x 256 B (mode 1) — the residual-stream epilogue (out = resid + x).
+template <int MODE>
+__global__ __launch_bounds__(512) void rmw(const float* in, float* out, int M, int N) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int ntn = N / 256;
+  const int tm = blockIdx.x / ntn, tn = blockIdx.x % ntn;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wm = w >> 2, wn = w & 3;
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {          // 8 groups of 4 instructions = 32 per wave (128 x 64 fp32 wave tile)
+    f4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int row, col;
+      if (MODE == 0) { row = wm * 128 + g * 16 + (lane & 15); col = wn * 64 + k * 16 + (lane >> 4) * 4; }
+      else { row = wm * 128 + (g * 4 + k) * 4 + (lane >> 4); col = wn * 64 + (lane & 15) * 4; }
+      v[k] = *(const f4*)(in + (size_t)(tm * 256 + row) * N + tn * 256 + col);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int row, col;
+      if (MODE == 0) { row = wm * 128 + g * 16 + (lane & 15); col = wn * 64 + k * 16 + (lane >> 4) * 4; }
+      else { row = wm * 128 + (g * 4 + k) * 4 + (lane >> 4); col = wn * 64 + (lane & 15) * 4; }
+      __builtin_nontemporal_store(v[k] + 1.0f, (f4*)(out + (size_t)(tm * 256 + row) * N + tn * 256 + col));
+    }
+  }
+}
+template <int MODE> void run_rmw(float* a, float* b, int M, int N) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  const int grid = (M / 256) * (N / 256);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((rmw<MODE>), dim3(grid), dim3(512), 0, 0, a, b, M, N);
+  hipEventRecord(e0);
+  for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((rmw<MODE>), dim3(grid), dim3(512), 0, 0, a, b, M, N);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  printf("fp32 rmw N=%d mode %d: %7.1f us  %5.2f TB/s (read+write)\n", N, MODE, ms * 50, (double)M * N * 8 / (ms / 20 * 1e-3) / 1e12);
+}
 template <int MODE, int NT_> void run(unsigned short* d, int M, int N) {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   const int grid = (M / 256) * (N / 256);
@@ -46,5 +84,7 @@ int main() {
   for (int N : {768, 3072}) {
     run<0, 0>(d, M, N); run<0, 1>(d, M, N); run<1, 0>(d, M, N); run<1, 1>(d, M, N); run<2, 0>(d, M, N); run<2, 1>(d, M, N);
   }
+  float *fa, *fb; hipMalloc(&fa, (size_t)M * 768 * 4); hipMalloc(&fb, (size_t)M * 768 * 4);
+  run_rmw<0>(fa, fb, M, 768); run_rmw<1>(fa, fb, M, 768); run_rmw<0>(fa, fa, M, 768); run_rmw<1>(fa, fa, M, 768);
   return 0;
 }
