@@ -1,0 +1,59 @@
+"""CPU: checkpoint interchange — Engine.save-style files and local hub-format snapshots load into the
+drop-in modules with the reference's / transformers' key names (host logic only, no kernels)."""
+import torch
+
+import lc2is_amd.nn as N
+from lc2is_amd import checkpoint as C
+from lc2is_amd.nn.clip import ClipArch
+
+
+def _tiny_arches():
+    v = ClipArch(64, 1, 1, 128)
+    t = ClipArch(64, 1, 1, 128, vocab=64, max_pos=16, eos_token_id=63)
+    return v, t
+
+
+def test_engine_style_checkpoint_roundtrip(tmp_path):
+    v, t = _tiny_arches()
+    protos = torch.randn(5, 64)
+    m = N.BaseModelWithText(16, 64, 16, vision_arch=v, text_arch=t, nhead=1, dim_feedforward=128, out_dim=64, prototypes=protos)
+    f = C.save_checkpoint(m, tmp_path, 7)
+    assert f == tmp_path / "checkpoints" / "step-7.pt"                          # engine.py:189 naming
+    m2 = N.BaseModelWithText(16, 64, 16, vision_arch=v, text_arch=t, nhead=1, dim_feedforward=128, out_dim=64, prototypes=torch.zeros(5, 64))
+    res = C.load_checkpoint(m2, f)
+    assert not res.missing_keys and not res.unexpected_keys
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+
+
+def test_local_hub_snapshot_into_towers(tmp_path):
+    from safetensors.torch import save_file
+    v, t = _tiny_arches()
+    vis = N.ImageEncoderCLIP(in_size=64, patch_size=16, arch=v)
+    txt = N.TextEncoderCLIP(patch_size=16, arch=t)
+    hub = {}
+    for k, p in vis.state_dict().items():
+        hub["vision_model." + k[len("enc."):]] = p.clone() + 1
+    for k, p in txt.state_dict().items():
+        hub["text_model." + k[len("enc."):]] = p.clone() + 2
+    hub["logit_scale"] = torch.tensor(1.0)
+    hub["visual_projection.weight"] = torch.zeros(4, 64)
+    d = tmp_path / "clip"
+    d.mkdir()
+    save_file(hub, str(d / "model.safetensors"))
+    ref_v = {k: p.clone() for k, p in vis.state_dict().items()}
+    ref_t = {k: p.clone() for k, p in txt.state_dict().items()}
+    C.load_pretrained_dir(vis, d)
+    C.load_pretrained_dir(txt, d)
+    assert all(torch.equal(vis.state_dict()[k], ref_v[k] + 1) for k in ref_v)
+    assert all(torch.equal(txt.state_dict()[k], ref_t[k] + 2) for k in ref_t)
+    # Swin: classification-checkpoint layout ("swin." prefix + classifier head) in pytorch_model.bin
+    sw = N.SwinTransformer(N.SwinArch(32, (2, 2, 2, 2), (1, 2, 4, 8), 5), drop_path_rate=0.0)
+    ref_s = {k: p.clone() for k, p in sw.state_dict().items()}
+    hub_s = {"swin." + k[len("encoder."):]: p.clone() - 1 for k, p in ref_s.items()}
+    hub_s["classifier.weight"] = torch.zeros(3, 256)
+    d2 = tmp_path / "swin"
+    d2.mkdir()
+    torch.save(hub_s, d2 / "pytorch_model.bin")
+    C.load_pretrained_dir(sw, d2)
+    assert all(torch.equal(sw.state_dict()[k], ref_s[k] - 1) for k in ref_s)
