@@ -17,6 +17,53 @@ from torch import nn
 from .. import ops
 
 
+import os as _os
+
+# Weight gradients are consumed only by the optimizer, so they run on a side HIP stream beside the dgrad chain: the wgrad
+# GEMM's tiles fill the CUs that the activation-gradient GEMMs leave idle in their last, partly empty round of tiles, and
+# the small ordered-reduce launches leave the critical path.  Joined in HipModule._grads_ready (end of a module's backward).
+_WGRAD_SIDE = _os.environ.get("LC2IS_WGRAD_STREAM", "1") != "0"
+_wgrad_streams: dict = {}
+
+
+def wgrad_stream(device) -> torch.cuda.Stream:
+    s = _wgrad_streams.get(device)
+    if s is None:
+        s = _wgrad_streams[device] = torch.cuda.Stream(device)
+    return s
+
+
+class _on_wgrad_stream:
+    """Context: run the enclosed launches on the wgrad stream after everything queued so far on the current one; the
+    operand tensors are kept from being recycled by the caching allocator until the side stream has read them."""
+
+    def __init__(self, *tensors):
+        self.tensors = [t for t in tensors if t is not None]
+
+    def __enter__(self):
+        if not _WGRAD_SIDE or torch.cuda.is_current_stream_capturing():
+            self.ctx = None
+            return self
+        dev = self.tensors[0].device
+        side = wgrad_stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        for t in self.tensors:
+            t.record_stream(side)
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
+def join_wgrad_stream(device) -> None:
+    if _WGRAD_SIDE and device in _wgrad_streams:
+        torch.cuda.current_stream(device).wait_stream(_wgrad_streams[device])
+
+
 def require_cuda(t: torch.Tensor, what: str) -> None:
     if not t.is_cuda:
         raise RuntimeError(
@@ -66,6 +113,8 @@ class HipModule(nn.Module):
         pass
 
     def _grads_ready(self):
+        if self._sh_device is not None:
+            join_wgrad_stream(self._sh_device)     # this module's weight gradients are complete on the current stream
         if self._grad_ready_cb is not None:
             self._grad_ready_cb(self)
 
@@ -90,20 +139,20 @@ def grad_buf(p: torch.Tensor):
 
 
 def linear_bwd_params(dy_bf16: torch.Tensor, x_bf16: torch.Tensor, weight: nn.Parameter, bias: nn.Parameter | None):
-    """dW = dy^T x, db = colsum(dy), written into the parameters' gradient buffers."""
+    """dW = dy^T x, db = colsum(dy), written into the parameters' gradient buffers (on the wgrad side stream)."""
     want_b = bias is not None and bias.requires_grad
     if weight.requires_grad:
         g, acc = grad_buf(weight)
-        gb = None
-        if want_b:
-            gb, accb = grad_buf(bias)
-            if accb != acc:      # mixed gradient state: fall back to the separate column-sum launch
+        gb, accb = grad_buf(bias) if want_b else (None, False)
+        with _on_wgrad_stream(dy_bf16, x_bf16):
+            if gb is not None and accb != acc:      # mixed gradient state: fall back to the separate column-sum launch
                 ops.colsum(dy_bf16, gb, accumulate=accb)
                 gb = None
-        ops.gemm_tn(dy_bf16, x_bf16, g.reshape(g.shape[0], -1), accumulate=acc, db=gb)
+            ops.gemm_tn(dy_bf16, x_bf16, g.reshape(g.shape[0], -1), accumulate=acc, db=gb)
     elif want_b:
         g, acc = grad_buf(bias)
-        ops.colsum(dy_bf16, g, accumulate=acc)
+        with _on_wgrad_stream(dy_bf16):
+            ops.colsum(dy_bf16, g, accumulate=acc)
 
 
 def vec_grad(p: nn.Parameter | None):
