@@ -19,10 +19,10 @@ from .. import ops
 
 import os as _os
 
-# Weight gradients are consumed only by the optimizer, so they run on a side HIP stream beside the dgrad chain: the wgrad
-# GEMM's tiles fill the CUs that the activation-gradient GEMMs leave idle in their last, partly empty round of tiles, and
-# the small ordered-reduce launches leave the critical path.  Joined in HipModule._grads_ready (end of a module's backward).
-_WGRAD_SIDE = _os.environ.get("LC2IS_WGRAD_STREAM", "1") != "0"
+# Experiment (LC2IS_WGRAD_STREAM=1): weight gradients are consumed only by the optimizer, so they can run on a side HIP
+# stream beside the dgrad chain (joined in HipModule._grads_ready).  Measured +0.3 % images/s on one box: the big GEMMs
+# saturate the chip either way, and sharing CUs stretches every co-running kernel — off by default.
+_WGRAD_SIDE = _os.environ.get("LC2IS_WGRAD_STREAM", "0") == "1"
 _wgrad_streams: dict = {}
 
 
@@ -139,7 +139,7 @@ def grad_buf(p: torch.Tensor):
 
 
 def linear_bwd_params(dy_bf16: torch.Tensor, x_bf16: torch.Tensor, weight: nn.Parameter, bias: nn.Parameter | None):
-    """dW = dy^T x, db = colsum(dy), written into the parameters' gradient buffers (on the wgrad side stream)."""
+    """dW = dy^T x, db = colsum(dy), written into the parameters' gradient buffers."""
     want_b = bias is not None and bias.requires_grad
     if weight.requires_grad:
         g, acc = grad_buf(weight)
