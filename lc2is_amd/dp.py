@@ -21,7 +21,8 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, process_group=None, max_chunk_elems: int = 64 * 1024 * 1024) -> None:
+    def __init__(self, process_group=None, max_chunk_elems: int = 64 * 1024 * 1024,
+                 bucket_elems: int = 12 * 1024 * 1024) -> None:
         if not dist.is_available() or not dist.is_initialized():
             raise RuntimeError("GradReducer needs an initialised torch.distributed process group")
         self.group = process_group
@@ -31,6 +32,9 @@ class GradReducer:
         self._flat = None
         self._done = set()
         self._module_ranges = {}
+        self.bucket_elems = bucket_elems     # layers are reduced in buckets of >= this many elements (48 MB fp32): xGMI
+        self._bucket = {}                    # rings are per-link bound and want large messages, not one per layer
+        self._early = {}
 
     # -- wiring ------------------------------------------------------------------------------------------------
     def attach(self, model, arena) -> None:
@@ -45,6 +49,7 @@ class GradReducer:
             owned.update(id(p) for p in ps)
             self._module_ranges[id(m)] = (m, self._merge([arena.ranges[id(p)] for p in ps]), ps)
             m._grad_ready_cb = self._on_module_done
+            m._part_ready_cb = self._on_part_done
         rest = [p for p in model.parameters() if id(p) not in owned]  # e.g. class_prototypes of the composition
         self._module_ranges[id(model)] = (model, self._merge([arena.ranges[id(p)] for p in rest]), rest)
         model._grad_ready_cb = self._on_module_done
@@ -64,18 +69,60 @@ class GradReducer:
     def begin_step(self) -> None:
         self._pending.clear()
         self._done.clear()
+        self._bucket.clear()
+        self._early.clear()
+
+    def _zero_missing(self, params) -> None:
+        for p in params:  # parameters the graph never reached still need defined (zero) gradients
+            if p.grad is None:
+                p._lc2is_grad.zero_()
+                p.grad = p._lc2is_grad
+
+    def _on_part_done(self, module, part) -> None:
+        """A layer of `module` finished its backward while the rest of the module is still running: its slice of the
+        arena joins the module's bucket, and a full bucket is all-reduced now, under the remaining backward."""
+        key = id(module)
+        if key not in self._module_ranges or key in self._done:
+            return
+        ps = [p for p in part.parameters() if id(p) in self._arena.ranges]
+        self._zero_missing(ps)
+        b = self._bucket.setdefault(key, [])
+        b.extend(self._arena.ranges[id(p)] for p in ps)
+        if sum(hi - lo for lo, hi in b) >= self.bucket_elems:
+            self._flush_bucket(key)
+
+    def _flush_bucket(self, key) -> None:
+        b = self._bucket.pop(key, None)
+        if b:
+            merged = self._merge(b)
+            self.reduce_ranges(self._flat, merged)
+            self._early.setdefault(key, []).extend(merged)
+
+    @staticmethod
+    def _subtract(ranges, done):
+        """ranges minus the already reduced sub-ranges (both lists of half-open intervals)."""
+        out = []
+        for lo, hi in ranges:
+            cur = lo
+            for a, b in sorted(done):
+                if b <= cur or a >= hi:
+                    continue
+                if a > cur:
+                    out.append((cur, a))
+                cur = max(cur, b)
+            if cur < hi:
+                out.append((cur, hi))
+        return out
 
     def _on_module_done(self, module) -> None:
         key = id(module)
         if key in self._done or key not in self._module_ranges:
             return
+        self._flush_bucket(key)
         self._done.add(key)
         _, ranges, params = self._module_ranges[key]
-        for p in params:  # parameters the graph never reached still need defined (zero) gradients
-            if p.grad is None:
-                p._lc2is_grad.zero_()
-                p.grad = p._lc2is_grad
-        self.reduce_ranges(self._flat, ranges)
+        self._zero_missing(params)
+        self.reduce_ranges(self._flat, self._subtract(ranges, self._early.get(key, [])))
 
     def reduce_ranges(self, flat: torch.Tensor, ranges) -> None:
         for lo, hi in ranges:
@@ -87,8 +134,9 @@ class GradReducer:
         """Reduce whatever has not been reduced yet, then make the compute stream wait for every collective."""
         for key, (_, ranges, _) in self._module_ranges.items():
             if key not in self._done:
+                self._flush_bucket(key)
                 self._done.add(key)
-                self.reduce_ranges(self._flat, ranges)
+                self.reduce_ranges(self._flat, self._subtract(ranges, self._early.get(key, [])))
         for w in self._pending:
             w.wait()
         self._pending.clear()

@@ -82,6 +82,7 @@ class HipModule(nn.Module):
         self._sh_device = None
         self._sh_ptrs = []
         self._grad_ready_cb = None  # set by dp.GradReducer: called when this module's backward is complete
+        self._part_ready_cb = None  # set by dp.GradReducer: called when a sub-module's (a layer's) gradients are complete
 
     # subclasses: return (namespace_dict, entries) where entries = [(param, dst, dstT)]
     def _build_shadows(self, device):  # pragma: no cover - abstract
@@ -117,6 +118,13 @@ class HipModule(nn.Module):
             join_wgrad_stream(self._sh_device)     # this module's weight gradients are complete on the current stream
         if self._grad_ready_cb is not None:
             self._grad_ready_cb(self)
+
+    def _part_grads_ready(self, part: nn.Module):
+        """A layer of this module has finished its backward (all its gradient kernels are queued on the current stream)."""
+        if self._part_ready_cb is not None:
+            if self._sh_device is not None:
+                join_wgrad_stream(self._sh_device)
+            self._part_ready_cb(self, part)
 
     def invalidate_shadows(self):
         """Call after changing parameters behind torch's back (the fused optimizer kernels do)."""

@@ -180,7 +180,7 @@ def _stack_fwd(x, stack: _Stack, sh, a: ClipArch, B: int, S: int, kbias, causal:
     return x, saved
 
 
-def _stack_bwd(g32, g16, stack: _Stack, sh, saved, a: ClipArch, B: int, S: int, kbias, causal: bool):
+def _stack_bwd(g32, g16, stack: _Stack, sh, saved, a: ClipArch, B: int, S: int, kbias, causal: bool, on_layer_done=None):
     """Backward of _stack_fwd.  g32/g16: gradient wrt the stack output (fp32 + bf16 twin).
     Returns the gradient wrt the stack input as (fp32, bf16)."""
     C, H = a.hidden, a.heads
@@ -211,6 +211,8 @@ def _stack_bwd(g32, g16, stack: _Stack, sh, saved, a: ClipArch, B: int, S: int, 
         db, _ = vec_grad(layer.layer_norm1.bias)
         g32, g16, _, _ = ops.layernorm_bwd(dh, x, layer.layer_norm1.weight, m1, r1, dres=gm32, dgamma=dg, dbeta=db,
                                            accumulate=accg, need_param_grads=dg is not None)
+        if on_layer_done is not None:      # every gradient of this layer is queued: the DP reducer may start on its slice
+            on_layer_done(layer)
     return g32, g16
 
 
@@ -342,7 +344,8 @@ class ImageEncoderCLIP(HipModule):
             g32 = torch.zeros(B * (P + 1), C, dtype=torch.float32, device=gout.device)
             ops.rows_copy(gout.reshape(B * P, C).float().contiguous(), P, 0, P + 1, 1, B, P, dst_f32=g32)
         g16 = ops.cast_bf16(g32)
-        g32, _ = _stack_bwd(g32, g16, self.enc.encoder, sh["layers"], saved["layers"], a, B, P + 1, None, False)
+        g32, _ = _stack_bwd(g32, g16, self.enc.encoder, sh["layers"], saved["layers"], a, B, P + 1, None, False,
+                            on_layer_done=self._part_grads_ready)
         dg, accg = vec_grad(self.enc.pre_layrnorm.weight)
         db, _ = vec_grad(self.enc.pre_layrnorm.bias)
         dx0, _, _, _ = ops.layernorm_bwd(g32, saved["x0"], self.enc.pre_layrnorm.weight, saved["m0"], saved["r0"],
@@ -449,7 +452,8 @@ class TextEncoderCLIP(HipModule):
         g32, g16, _, _ = ops.layernorm_bwd(gout.reshape(B * L, C).float().contiguous(), saved["xf"], fl.weight,
                                            saved["mf"], saved["rf"], dgamma=dg, dbeta=db, accumulate=accg,
                                            need_param_grads=dg is not None)
-        g32, _ = _stack_bwd(g32, g16, self.enc.encoder, sh["layers"], saved["layers"], a, B, L, saved["kbias"], True)
+        g32, _ = _stack_bwd(g32, g16, self.enc.encoder, sh["layers"], saved["layers"], a, B, L, saved["kbias"], True,
+                            on_layer_done=self._part_grads_ready)
         emb = self.enc.embeddings
         if emb.token_embedding.weight.requires_grad:
             gtok, acct = grad_buf(emb.token_embedding.weight)

@@ -34,7 +34,7 @@ def _worker(rank, world, port, q):
     from lc2is_amd.dp import GradReducer
     from lc2is_amd.step import TrainStep
     m, fx = _build(dev)
-    red = GradReducer()
+    red = GradReducer(bucket_elems=100_000)     # small buckets: the per-layer early reductions of the towers are exercised
     ts = TrainStep(m, optimizer="sgd", lr=0.05, reducer=red)
     red.broadcast_params(ts.arena.flat, src=0)
     inputs = {k: fx[k][rank:rank + 1].to(dev) for k in ("pixel_values", "input_ids", "attention_mask")}

@@ -8,7 +8,8 @@ from bench_kernels import timeit
 
 cfgs = [int(c) for c in sys.argv[1].split(",")] if len(sys.argv) > 1 else [4, 9]
 dev = torch.device("cuda:0")
-M = 32800
+import os
+M = int(os.environ.get("GEMM_M", "32800"))
 cases = [("qkv", 2304, 768, "plain"), ("proj", 768, 768, "resid"), ("fc1", 3072, 768, "act"), ("fc2", 768, 3072, "resid"),
          ("fc1g", 3072, 768, "act5"), ("dfc2", 3072, 768, "dact"), ("dfc2m", 3072, 768, "dmul"), ("dfc1", 768, 3072, "plain"),
          ("dqkv", 768, 2304, "plain")]
