@@ -77,6 +77,18 @@ int lc2is_gemm_tn_bf16(const void* dY, int ldy, const void* X, int ldx, float* d
                        int N, int K, int accumulate, void* workspace, size_t workspace_bytes,
                        lc2is_stream_t stream);
 
+/* Grouped form: up to 8 weight gradients (one transformer layer: q, k, v, out-proj, fc1, fc2 — each the autograd of an
+ * nn.Linear call listed above) in ONE grid and one ordered-reduce launch.  Every N and K must be a multiple of 256
+ * (LC2IS_ERR_UNSUPPORTED otherwise: call lc2is_gemm_tn_bf16 per problem).  Same results contract: fp32, bitwise
+ * reproducible, db (optional) = column sums of dY, `accumulate` adds to dW / db. */
+typedef struct lc2is_tn_problem {
+  const void* dY; const void* X; float* dW; float* db;
+  int ldy, ldx, ldw, M, N, K, accumulate;
+} lc2is_tn_problem;
+size_t lc2is_gemm_tn_grouped_workspace_bytes(const lc2is_tn_problem* problems, int n);
+int lc2is_gemm_tn_grouped(const lc2is_tn_problem* problems, int n, void* workspace, size_t workspace_bytes,
+                          lc2is_stream_t stream);
+
 /* db[N] (fp32) = column sums of dY[M,N] (bias gradient). workspace >= lc2is_colsum_workspace_bytes. */
 size_t lc2is_colsum_workspace_bytes(int M, int N);
 int lc2is_colsum_bf16(const void* dY, int ldy, float* db, int M, int N, int accumulate, void* workspace,

@@ -258,18 +258,16 @@ __device__ __forceinline__ void td_dma(const bf16_t* dY, unsigned y_bytes, const
 #endif
 }
 
-__global__ __launch_bounds__(512, 2) void gemm_tn_dma_kernel(const bf16_t* __restrict__ dY, int ldy,
-                                                              const bf16_t* __restrict__ X, int ldx, float* out, int ldo,
-                                                              size_t split_stride, float* bias_out,
-                                                              size_t bias_split_stride, int M, int N, int K, int ntn,
-                                                              int ntk, int chunk, int accumulate) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void tn_dma_body(const bf16_t* __restrict__ dY, int ldy, const bf16_t* __restrict__ X, int ldx,
+                                            float* out, int ldo, size_t split_stride, float* bias_out,
+                                            size_t bias_split_stride, int M, int N, int K, int ntn, int ntk, int chunk,
+                                            int accumulate, int block, char* smem) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wk = wid >> 2, wn = wid & 3;
   const int tiles = ntn * ntk;
-  const int split = blockIdx.x / tiles;
-  const int tile = blockIdx.x % tiles;
+  const int split = block / tiles;
+  const int tile = block % tiles;
   const int n0 = (tile / ntk) * TD_BN, k0 = (tile % ntk) * TD_BK;
   const int m_begin = split * chunk;
   int m_end = m_begin + chunk;
@@ -361,6 +359,79 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_dma_kernel(const bf16_t* __res
       if (accumulate) v += *(const f32x4_t*)dst;
       *(f32x4_t*)dst = v;
     }
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_tn_dma_kernel(const bf16_t* __restrict__ dY, int ldy,
+                                                              const bf16_t* __restrict__ X, int ldx, float* out, int ldo,
+                                                              size_t split_stride, float* bias_out,
+                                                              size_t bias_split_stride, int M, int N, int K, int ntn,
+                                                              int ntk, int chunk, int accumulate) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  tn_dma_body(dY, ldy, X, ldx, out, ldo, split_stride, bias_out, bias_split_stride, M, N, K, ntn, ntk, chunk, accumulate,
+              blockIdx.x, smem);
+}
+
+// ---- grouped launch: the weight gradients of one transformer layer in ONE grid ---------------------------------------
+// A ViT layer has six weight gradients over the same tokens (q, k, v, out-proj: 9 tiles each; fc1, fc2: 36 each).  Launched
+// one by one each fills the chip only by cutting M into 7-28 slabs, so every block is short (19-74 steps) against a fixed
+// prologue + 256-KiB epilogue, and each launch drags its own ordered-reduce launch.  Grouped, the 108 tiles need only a
+// 2-way M split to give every CU a long block: fewer, longer blocks, a quarter of the slab traffic, one reduce launch.
+constexpr int TG_MAX = 8;
+struct TnGroupProb {
+  const bf16_t* dY; const bf16_t* X; float* out; float* bias_out; float* dW; float* db;
+  size_t split_stride, bias_split_stride;
+  int ldy, ldx, ldo, ldw, M, N, K, ntn, ntk, chunk, splits, accumulate;
+  int blk_end;      // exclusive end of this problem's block range in the main grid
+  int red_end;      // ... and in the reduce grid
+  int red_blocks;   // slab blocks of the reduce grid (the rest of the problem's range sums the bias partials)
+};
+struct TnGroup {
+  int n;
+  TnGroupProb p[TG_MAX];
+};
+
+__global__ __launch_bounds__(512, 2) void gemm_tn_grouped_kernel(TnGroup g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int i = 0, begin = 0;
+#pragma unroll 1
+  while (i < g.n - 1 && (int)blockIdx.x >= g.p[i].blk_end) { begin = g.p[i].blk_end; ++i; }
+  const TnGroupProb& q = g.p[i];
+  tn_dma_body(q.dY, q.ldy, q.X, q.ldx, q.out, q.ldo, q.split_stride, q.bias_out, q.bias_split_stride, q.M, q.N, q.K, q.ntn,
+              q.ntk, q.chunk, q.splits == 1 ? q.accumulate : 0, (int)blockIdx.x - begin, smem);
+}
+
+__global__ __launch_bounds__(256) void slab_reduce_grouped_kernel(TnGroup g) {
+  int i = 0, begin = 0;
+#pragma unroll 1
+  while (i < g.n - 1 && (int)blockIdx.x >= g.p[i].red_end) { begin = g.p[i].red_end; ++i; }
+  const TnGroupProb& q = g.p[i];
+  if (q.splits <= 1) return;
+  const int b = (int)blockIdx.x - begin;
+  if (b >= q.red_blocks) {                     // fused bias-gradient partials, one column per thread, fixed order
+    const int n = (b - q.red_blocks) * 256 + threadIdx.x;
+    if (q.db && n < q.N) {
+      float t = 0.f;
+      for (int sp = 0; sp < q.splits; ++sp) t += q.bias_out[(size_t)sp * q.bias_split_stride + n];
+      q.db[n] = q.accumulate ? q.db[n] + t : t;
+    }
+    return;
+  }
+  const int K4 = q.K >> 2;
+  const size_t total = (size_t)q.N * K4;
+  for (size_t idx = (size_t)b * 256 + threadIdx.x; idx < total; idx += (size_t)q.red_blocks * 256) {
+    const int n = (int)(idx / K4), k4 = (int)(idx % K4);
+    float4 s4 = *(reinterpret_cast<const float4*>(q.out + (size_t)n * q.K) + k4);
+    for (int sp = 1; sp < q.splits; ++sp) {
+      const float4 v = *reinterpret_cast<const float4*>(q.out + sp * q.split_stride + (size_t)n * q.K + 4 * k4);
+      s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
+    }
+    float4* dst = reinterpret_cast<float4*>(q.dW + (size_t)n * q.ldw) + k4;
+    if (q.accumulate) {
+      const float4 d = *dst;
+      s4.x += d.x; s4.y += d.y; s4.z += d.z; s4.w += d.w;
+    }
+    *dst = s4;
   }
 }
 
@@ -500,6 +571,111 @@ extern "C" int lc2is_gemm_tn_bf16(const void* dY, int ldy, const void* X, int ld
   const int bias_blocks = db ? (N + 255) / 256 : 0;
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(rgrid + bias_blocks), dim3(256), 0, stream, (const float*)workspace,
                      p.splits, (size_t)N * K, dW, ldw, N, K, accumulate, (const float*)bias_ws, db, bias_blocks);
+  return lc2is_check_launch();
+}
+
+// ---- grouped weight gradients -------------------------------------------------------------------------------------
+namespace {
+struct TgPlan { int splits; size_t ws_floats; };
+
+inline int tg_valid(const lc2is_tn_problem* pr, int n) {
+  if (!pr || n <= 0 || n > TG_MAX) return LC2IS_ERR_UNSUPPORTED;
+  for (int i = 0; i < n; ++i) {
+    const lc2is_tn_problem& q = pr[i];
+    if (!q.dY || !q.X || !q.dW) return LC2IS_ERR_NULL;
+    if (q.M <= 0 || q.N <= 0 || q.K <= 0 || q.N % 256 || q.K % 256) return LC2IS_ERR_UNSUPPORTED;
+    if (q.ldy < q.N || q.ldx < q.K || q.ldw < q.K || q.ldy % 8 || q.ldx % 8 || q.ldw % 4) return LC2IS_ERR_SHAPE;
+    if ((double)(q.M + 64) * q.ldy * 2.0 >= 2147483648.0 || (double)(q.M + 64) * q.ldx * 2.0 >= 2147483648.0)
+      return LC2IS_ERR_UNSUPPORTED;
+  }
+  return LC2IS_OK;
+}
+
+// one M-split count for the whole group: minimise  rounds x (longest block + fixed per-block cost)  + slab traffic,
+// in units of one 64-row step of a 256x256 tile (~1.65 us); 13 steps ~ prologue + 256-KiB epilogue of a block.
+inline TgPlan tg_plan(const lc2is_tn_problem* pr, int n) {
+  long tiles = 0;
+  double wbytes = 0;
+  int max_steps = 0, max_splits = 1 << 30;
+  for (int i = 0; i < n; ++i) {
+    tiles += (long)(pr[i].N / 256) * (pr[i].K / 256);
+    wbytes += 4.0 * pr[i].N * pr[i].K;
+    const int steps = (pr[i].M + TN_BM - 1) / TN_BM;
+    if (steps > max_steps) max_steps = steps;
+    const int ms = (pr[i].M + 511) / 512;
+    if (ms < max_splits) max_splits = ms;
+  }
+  if (max_splits > 32) max_splits = 32;
+  if (max_splits < 1) max_splits = 1;
+  int best = 1;
+  double best_t = 1e300;
+  for (int sp = 1; sp <= max_splits; ++sp) {
+    const long blocks = tiles * sp;
+    const double rounds = (double)((blocks + 255) / 256);
+    const double t = rounds * ((max_steps + sp - 1) / sp + 13.0) + (sp > 1 ? sp * wbytes * 2.0 / 4.0e12 / 1.65e-6 : 0.0);
+    if (t < best_t) { best_t = t; best = sp; }
+  }
+  TgPlan pl{best, 0};
+  if (best > 1)
+    for (int i = 0; i < n; ++i) pl.ws_floats += (size_t)best * pr[i].N * ((size_t)pr[i].K + 1);
+  return pl;
+}
+}  // namespace
+
+extern "C" size_t lc2is_gemm_tn_grouped_workspace_bytes(const lc2is_tn_problem* problems, int n) {
+  if (tg_valid(problems, n) != LC2IS_OK) return 0;
+  return tg_plan(problems, n).ws_floats * sizeof(float);
+}
+
+extern "C" int lc2is_gemm_tn_grouped(const lc2is_tn_problem* problems, int n, void* workspace, size_t workspace_bytes,
+                                     lc2is_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = tg_valid(problems, n);
+  if (rc) return rc;
+  const TgPlan pl = tg_plan(problems, n);
+  if (pl.ws_floats && (!workspace || workspace_bytes < pl.ws_floats * sizeof(float))) return LC2IS_ERR_WORKSPACE;
+  TnGroup g{};
+  g.n = n;
+  float* ws = (float*)workspace;
+  int blk = 0, red = 0;
+  for (int i = 0; i < n; ++i) {
+    const lc2is_tn_problem& q = problems[i];
+    TnGroupProb& d = g.p[i];
+    d.dY = (const bf16_t*)q.dY; d.X = (const bf16_t*)q.X; d.dW = q.dW; d.db = q.db;
+    d.ldy = q.ldy; d.ldx = q.ldx; d.ldw = q.ldw; d.M = q.M; d.N = q.N; d.K = q.K; d.accumulate = q.accumulate;
+    d.ntn = q.N / 256; d.ntk = q.K / 256;
+    int chunk = (q.M + pl.splits - 1) / pl.splits;
+    chunk = (chunk + TN_BM - 1) / TN_BM * TN_BM;
+    d.chunk = chunk;
+    d.splits = (q.M + chunk - 1) / chunk;
+    if (d.splits > 1) {
+      d.out = ws; d.ldo = q.K; d.split_stride = (size_t)q.N * q.K;
+      ws += (size_t)d.splits * q.N * q.K;
+      d.bias_out = q.db ? ws : nullptr; d.bias_split_stride = (size_t)q.N;
+      ws += (size_t)d.splits * q.N;
+    } else {
+      d.out = q.dW; d.ldo = q.ldw; d.split_stride = 0; d.bias_out = q.db; d.bias_split_stride = 0;
+    }
+    blk += d.ntn * d.ntk * d.splits;
+    d.blk_end = blk;
+    const size_t total4 = (size_t)q.N * q.K / 4;
+    int rb = (int)((total4 + 255) / 256);
+    if (rb > 1024) rb = 1024;
+    d.red_blocks = d.splits > 1 ? rb : 0;
+    red += d.splits > 1 ? rb + (q.db ? (q.N + 255) / 256 : 0) : 0;
+    d.red_end = red;
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm_tn_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            2 * TD_STAGE) != hipSuccess)
+      return LC2IS_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(blk), dim3(512), 2 * TD_STAGE, stream, g);
+  rc = lc2is_check_launch();
+  if (rc || red == 0) return rc;
+  hipLaunchKernelGGL(slab_reduce_grouped_kernel, dim3(red), dim3(256), 0, stream, g);
   return lc2is_check_launch();
 }
 

@@ -146,12 +146,51 @@ def grad_buf(p: torch.Tensor):
     return p.grad, True
 
 
+class WgradBatch:
+    """``with WgradBatch():`` defers the weight-gradient GEMMs requested by ``linear_bwd_params`` inside the block and
+    launches them together at exit (``ops.gemm_tn_grouped``: one grid + one ordered reduce for a whole transformer layer).
+    The operands are referenced by the batch until then.  Problems the grouped kernel does not take (N or K not a
+    multiple of 256, few tokens, mixed accumulate state) are launched right away as before."""
+
+    _active = None
+
+    def __init__(self, enabled: bool = True):
+        self.enabled = enabled and _os.environ.get("LC2IS_WGRAD_GROUPED", "1") != "0"
+        self.items = []
+
+    def __enter__(self):
+        if self.enabled:
+            self._prev, WgradBatch._active = WgradBatch._active, self
+        return self
+
+    def __exit__(self, exc_type, *exc):
+        if self.enabled:
+            WgradBatch._active = self._prev
+            if exc_type is None:
+                self.flush()
+        return False
+
+    def flush(self):
+        items, self.items = self.items, []
+        for i in range(0, len(items), ops.GROUP_MAX):
+            chunk = items[i:i + ops.GROUP_MAX]
+            if len(chunk) == 1:
+                dy, x, g, gb, acc = chunk[0]
+                ops.gemm_tn(dy, x, g, accumulate=acc, db=gb)
+            else:
+                ops.gemm_tn_grouped(chunk)
+
+
 def linear_bwd_params(dy_bf16: torch.Tensor, x_bf16: torch.Tensor, weight: nn.Parameter, bias: nn.Parameter | None):
     """dW = dy^T x, db = colsum(dy), written into the parameters' gradient buffers."""
     want_b = bias is not None and bias.requires_grad
     if weight.requires_grad:
         g, acc = grad_buf(weight)
         gb, accb = grad_buf(bias) if want_b else (None, False)
+        batch = WgradBatch._active
+        if batch is not None and (gb is None or accb == acc) and ops.gemm_tn_groupable(dy_bf16, x_bf16):
+            batch.items.append((dy_bf16, x_bf16, g.reshape(g.shape[0], -1), gb, acc))
+            return
         with _on_wgrad_stream(dy_bf16, x_bf16):
             if gb is not None and accb != acc:      # mixed gradient state: fall back to the separate column-sum launch
                 ops.colsum(dy_bf16, gb, accumulate=accb)

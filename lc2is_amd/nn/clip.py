@@ -25,7 +25,7 @@ import torch
 from torch import nn
 
 from .. import ops
-from .base import HipModule, grad_buf, linear_bwd_params, require_cuda, vec_grad
+from .base import HipModule, WgradBatch, grad_buf, linear_bwd_params, require_cuda, vec_grad
 
 
 @dataclass
@@ -187,30 +187,31 @@ def _stack_bwd(g32, g16, stack: _Stack, sh, saved, a: ClipArch, B: int, S: int, 
     D = C // H
     scale = D ** -0.5
     for layer, s, sv in zip(reversed(stack.layers), reversed(sh), reversed(saved)):
-        x, m1, r1, h, qkv, o, lse, x_mid, m2, r2, h2, z, act = sv
-        at, mlp = layer.self_attn, layer.mlp
-        # x_out = x_mid + fc2(quick_gelu(fc1(LN2(x_mid))))
-        linear_bwd_params(g16, act, mlp.fc2.weight, mlp.fc2.bias)
-        dz, _, _ = ops.gemm_nt(g16, s["w2T"], None, act=ops.ACT_DQUICK_GELU, aux_in=z)
-        linear_bwd_params(dz, h2, mlp.fc1.weight, mlp.fc1.bias)
-        dh2, _, _ = ops.gemm_nt(dz, s["w1T"], None)
-        dg, accg = vec_grad(layer.layer_norm2.weight)
-        db, _ = vec_grad(layer.layer_norm2.bias)
-        gm32, gm16, _, _ = ops.layernorm_bwd(dh2, x_mid, layer.layer_norm2.weight, m2, r2, dres=g32, dgamma=dg,
-                                             dbeta=db, accumulate=accg, need_param_grads=dg is not None)
-        # x_mid = x + out_proj(attn(qkv(LN1(x))))
-        linear_bwd_params(gm16, o, at.out_proj.weight, at.out_proj.bias)
-        do, _, _ = ops.gemm_nt(gm16, s["woT"], None)
-        dqkv = torch.empty_like(qkv)
-        ops.attention_bwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o, do, lse, B, H, S, S, D, scale, causal=causal,
-                          kbias=kbias, dq=dqkv[:, :C], dk=dqkv[:, C:2 * C], dv=dqkv[:, 2 * C:])
-        for j, proj in enumerate((at.q_proj, at.k_proj, at.v_proj)):
-            linear_bwd_params(dqkv[:, j * C:(j + 1) * C], h, proj.weight, proj.bias)
-        dh, _, _ = ops.gemm_nt(dqkv, s["wqkvT"], None)
-        dg, accg = vec_grad(layer.layer_norm1.weight)
-        db, _ = vec_grad(layer.layer_norm1.bias)
-        g32, g16, _, _ = ops.layernorm_bwd(dh, x, layer.layer_norm1.weight, m1, r1, dres=gm32, dgamma=dg, dbeta=db,
-                                           accumulate=accg, need_param_grads=dg is not None)
+        with WgradBatch():   # the layer's six weight gradients leave as ONE grouped launch at the end of the block
+            x, m1, r1, h, qkv, o, lse, x_mid, m2, r2, h2, z, act = sv
+            at, mlp = layer.self_attn, layer.mlp
+            # x_out = x_mid + fc2(quick_gelu(fc1(LN2(x_mid))))
+            linear_bwd_params(g16, act, mlp.fc2.weight, mlp.fc2.bias)
+            dz, _, _ = ops.gemm_nt(g16, s["w2T"], None, act=ops.ACT_DQUICK_GELU, aux_in=z)
+            linear_bwd_params(dz, h2, mlp.fc1.weight, mlp.fc1.bias)
+            dh2, _, _ = ops.gemm_nt(dz, s["w1T"], None)
+            dg, accg = vec_grad(layer.layer_norm2.weight)
+            db, _ = vec_grad(layer.layer_norm2.bias)
+            gm32, gm16, _, _ = ops.layernorm_bwd(dh2, x_mid, layer.layer_norm2.weight, m2, r2, dres=g32, dgamma=dg,
+                                                 dbeta=db, accumulate=accg, need_param_grads=dg is not None)
+            # x_mid = x + out_proj(attn(qkv(LN1(x))))
+            linear_bwd_params(gm16, o, at.out_proj.weight, at.out_proj.bias)
+            do, _, _ = ops.gemm_nt(gm16, s["woT"], None)
+            dqkv = torch.empty_like(qkv)
+            ops.attention_bwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o, do, lse, B, H, S, S, D, scale, causal=causal,
+                              kbias=kbias, dq=dqkv[:, :C], dk=dqkv[:, C:2 * C], dv=dqkv[:, 2 * C:])
+            for j, proj in enumerate((at.q_proj, at.k_proj, at.v_proj)):
+                linear_bwd_params(dqkv[:, j * C:(j + 1) * C], h, proj.weight, proj.bias)
+            dh, _, _ = ops.gemm_nt(dqkv, s["wqkvT"], None)
+            dg, accg = vec_grad(layer.layer_norm1.weight)
+            db, _ = vec_grad(layer.layer_norm1.bias)
+            g32, g16, _, _ = ops.layernorm_bwd(dh, x, layer.layer_norm1.weight, m1, r1, dres=gm32, dgamma=dg, dbeta=db,
+                                               accumulate=accg, need_param_grads=dg is not None)
         if on_layer_done is not None:      # every gradient of this layer is queued: the DP reducer may start on its slice
             on_layer_done(layer)
     return g32, g16

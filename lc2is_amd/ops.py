@@ -56,6 +56,8 @@ _ARGTYPES = {
     "lc2is_cols_ce": [_P, _P, _P, _P, _F, _I, _I, _I, _I, _P],
     "lc2is_npair": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "lc2is_miou_counts": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "lc2is_gemm_tn_grouped_workspace_bytes": [_P, _I],
+    "lc2is_gemm_tn_grouped": [_P, _I, _P, _Z, _P],
     "lc2is_rows_gather": [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _P],
     "lc2is_resample_u8": [_P, _I, _I, _I, _P, _I, _I, _P, _P, _I, _P],
     "lc2is_gather2d_u8": [_P, _I, _I, _I, _P, _I, _I, _P, _P, _P],
@@ -180,6 +182,36 @@ def gemm_tn(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor | None = None, a
                                    int(accumulate), _ptr(ws), ws.numel(), _stream())
     _lib.check(rc, f"gemm_tn M={M} N={N} K={K}")
     return dw
+
+
+class TnProblem(C.Structure):
+    _fields_ = [("dY", C.c_void_p), ("X", C.c_void_p), ("dW", C.c_void_p), ("db", C.c_void_p), ("ldy", C.c_int),
+                ("ldx", C.c_int), ("ldw", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("accumulate", C.c_int)]
+
+
+GROUP_MAX = 8
+
+
+def gemm_tn_groupable(dy: torch.Tensor, x: torch.Tensor) -> bool:
+    return dy.shape[1] % 256 == 0 and x.shape[1] % 256 == 0 and dy.shape[0] >= 4096
+
+
+def gemm_tn_grouped(problems):
+    """problems: list of (dy [M,N] bf16, x [M,K] bf16, dw [N,K] fp32, db [N] fp32 or None, accumulate) with N, K
+    multiples of 256 (check with gemm_tn_groupable) — the weight gradients of one layer in one grid."""
+    if not 1 <= len(problems) <= GROUP_MAX:
+        raise RuntimeError("lc2is_amd.gemm_tn_grouped: 1..8 problems per launch")
+    arr = (TnProblem * len(problems))()
+    for i, (dy, x, dw, db, acc) in enumerate(problems):
+        _chk(dy, torch.bfloat16, "dy"); _chk(x, torch.bfloat16, "x"); _chk(dw, torch.float32, "dw"); _chk(db, torch.float32, "db", 1)
+        M, N = dy.shape
+        if x.shape[0] != M or tuple(dw.shape) != (N, x.shape[1]) or (db is not None and db.numel() != N):
+            raise RuntimeError("lc2is_amd.gemm_tn_grouped: shape mismatch")
+        arr[i] = TnProblem(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), _ld(dy), _ld(x), _ld(dw), M, N, x.shape[1], int(acc))
+    nbytes = _fn("lc2is_gemm_tn_grouped_workspace_bytes")(arr, len(problems))
+    ws = workspace(nbytes, problems[0][0].device, "gemm_tn_grouped")
+    rc = _fn("lc2is_gemm_tn_grouped")(arr, len(problems), _ptr(ws), ws.numel(), _stream())
+    _lib.check(rc, f"gemm_tn_grouped n={len(problems)}")
 
 
 def colsum(dy: torch.Tensor, db: torch.Tensor | None = None, accumulate: bool = False):

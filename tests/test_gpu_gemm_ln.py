@@ -212,3 +212,33 @@ def test_gemm_nt_pingpong_is_bitwise_equal_to_simple_pipeline(dev):
             for _ in range(5):
                 ob, of, _ = ops.gemm_nt(a, w, bias, out_bf16=True, out_f32=True, tile_cfg=cfg)
                 assert torch.equal(of, reff) and torch.equal(ob, ref), (M, N, K, cfg)
+
+
+def test_gemm_tn_grouped(dev):
+    """One grid for several weight gradients == the per-problem launches (fp32, reproducible; accumulate + fused bias)."""
+    from lc2is_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(11)
+    M = 4100
+    shapes = [(256, 768), (768, 256), (256, 256), (512, 256)]
+    probs, refs = [], []
+    for i, (N, K) in enumerate(shapes):
+        dy = _bf(torch.randn(M, N + 64, generator=g)).to(dev)[:, :N]            # strided view (ldy > N), like dqkv slices
+        x = _bf(torch.randn(M, K, generator=g)).to(dev)
+        acc = i % 2 == 1
+        dw = torch.full((N, K), 2.0, device=dev)
+        db = torch.full((N,), 3.0, device=dev) if i != 2 else None
+        probs.append((dy, x, dw, db, acc))
+        ref_w = dy.double().T @ x.double() + (2.0 if acc else 0.0)
+        ref_b = dy.double().sum(0) + (3.0 if acc else 0.0)
+        refs.append((ref_w, ref_b))
+    ops.gemm_tn_grouped(probs)
+    for (dy, x, dw, db, acc), (rw, rb) in zip(probs, refs):
+        assert _rel(dw, rw) < 1e-5
+        if db is not None:
+            assert _rel(db, rb) < 1e-5
+    again = [(dy, x, torch.full_like(dw, 2.0), None if db is None else torch.full_like(db, 3.0), acc) for dy, x, dw, db, acc in probs]
+    ops.gemm_tn_grouped(again)
+    for a, b in zip(again, probs):
+        assert torch.equal(a[2], b[2]) and (a[3] is None or torch.equal(a[3], b[3]))   # bitwise reproducible
+    with pytest.raises(RuntimeError):
+        ops.gemm_tn_grouped([(probs[0][0][:, :200], probs[0][1], torch.empty(200, 768, device=dev), None, False)] * 2)
