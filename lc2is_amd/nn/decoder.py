@@ -24,7 +24,7 @@ import torch
 from torch import nn
 
 from .. import ops
-from .base import HipModule, grad_buf, linear_bwd_params, require_cuda, vec_grad
+from .base import HipModule, WgradBatch, grad_buf, linear_bwd_params, require_cuda, vec_grad
 
 
 class _SelfAttnParams(nn.Module):
@@ -141,7 +141,13 @@ def _layer_fwd(x, mem16, layer: DecoderLayer, s, B, Sq, Sk, kbias, save):
     return x3, (sv if save else None)
 
 
-def _layer_bwd(g32, g16, dmem32, mem16, layer: DecoderLayer, s, sv, B, Sq, Sk, kbias):
+def _layer_bwd(g32, g16, dmem32, mem16, layer, s, sv, B, Sq, Sk, kbias):
+    """The layer's weight gradients are deferred and leave as one grouped launch (base.WgradBatch)."""
+    with WgradBatch():
+        return _layer_bwd_impl(g32, g16, dmem32, mem16, layer, s, sv, B, Sq, Sk, kbias)
+
+
+def _layer_bwd_impl(g32, g16, dmem32, mem16, layer: DecoderLayer, s, sv, B, Sq, Sk, kbias):
     """Backward of _layer_fwd; accumulates the memory gradient into dmem32 (fp32 [B*Sk, Ckv]).
     Returns (g32, g16) wrt the layer input."""
     C, H = layer.d_model, layer.nhead

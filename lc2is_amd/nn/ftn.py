@@ -25,7 +25,7 @@ import torch
 from torch import nn
 
 from .. import ops
-from .base import HipModule, grad_buf, linear_bwd_params, require_cuda, vec_grad
+from .base import HipModule, WgradBatch, grad_buf, linear_bwd_params, require_cuda, vec_grad
 from .hier import _PackedAttnParams, _packed_param_grads, _split_bias
 
 
@@ -96,7 +96,13 @@ def _std_layer_fwd(x32, x16, mem16, layer: _StdLayerParams, s, tag, B, P, K, sav
     return y32, y16, (sv if save else None)
 
 
-def _std_layer_bwd(g32, dmem32, mem16, layer: _StdLayerParams, s, tag, sv, B, P, K):
+def _std_layer_bwd(g32, dmem32, mem16, layer, s, tag, sv, B, P, K):
+    """The layer's weight gradients are deferred and leave as one grouped launch (base.WgradBatch)."""
+    with WgradBatch():
+        return _std_layer_bwd_impl(g32, dmem32, mem16, layer, s, tag, sv, B, P, K)
+
+
+def _std_layer_bwd_impl(g32, dmem32, mem16, layer: _StdLayerParams, s, tag, sv, B, P, K):
     """g32: gradient wrt the layer output; accumulates the memory gradient into dmem32; returns d/d(layer input)."""
     C, H = layer.d_model, layer.nhead
     D = C // H

@@ -24,7 +24,7 @@ import torch
 from torch import nn
 
 from .. import ops
-from .base import HipModule, grad_buf, linear_bwd_params, require_cuda, vec_grad
+from .base import HipModule, WgradBatch, grad_buf, linear_bwd_params, require_cuda, vec_grad
 
 
 def _isqrt(p: int) -> int:
@@ -175,7 +175,13 @@ def _packed_param_grads(attn: _PackedAttnParams, dq16, x_q16, dkv16, x_kv16, C):
         ops.colsum(dkv16, gb[C:], accumulate=accb)
 
 
-def _sr_layer_bwd(g32, dmem32, mem16, layer: _SRLayer, s, sv, B, P, K):
+def _sr_layer_bwd(g32, dmem32, mem16, layer, s, sv, B, P, K):
+    """The layer's weight gradients are deferred and leave as one grouped launch (base.WgradBatch)."""
+    with WgradBatch():
+        return _sr_layer_bwd_impl(g32, dmem32, mem16, layer, s, sv, B, P, K)
+
+
+def _sr_layer_bwd_impl(g32, dmem32, mem16, layer: _SRLayer, s, sv, B, P, K):
     """g32: gradient wrt the layer output (fp32).  Accumulates the text-memory gradient into dmem32.
     Returns the gradient wrt the layer input (fp32)."""
     C, H = layer.d_model, layer.nhead
