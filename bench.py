@@ -233,7 +233,7 @@ def main():
                          "avg_launch_us": gsum["seconds"] / max(gsum["launches"], 1) * 1e6,
                          "gemm_nt_time_share": gsum["seconds"] / timed_steps / (dt / args.steps)},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU baseline leg belongs to the N=1 line only
             try:
                 if args.patch != 16:
                     raise RuntimeError("cpu_baseline is defined for the headline ViT-B/16 workload only")

@@ -77,7 +77,7 @@ int lc2is_gemm_tn_bf16(const void* dY, int ldy, const void* X, int ldx, float* d
                        int N, int K, int accumulate, void* workspace, size_t workspace_bytes,
                        lc2is_stream_t stream);
 
-/* Grouped form: up to 8 weight gradients (one transformer layer: q, k, v, out-proj, fc1, fc2 — each the autograd of an
+/* Grouped form: up to 16 weight gradients (one or two transformer layers: q, k, v, out-proj, fc1, fc2 — each the autograd of an
  * nn.Linear call listed above) in ONE grid and one ordered-reduce launch.  Every N and K must be a multiple of 256
  * (LC2IS_ERR_UNSUPPORTED otherwise: call lc2is_gemm_tn_bf16 per problem).  Same results contract: fp32, bitwise
  * reproducible, db (optional) = column sums of dY, `accumulate` adds to dW / db. */

@@ -377,7 +377,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_dma_kernel(const bf16_t* __res
 // one by one each fills the chip only by cutting M into 7-28 slabs, so every block is short (19-74 steps) against a fixed
 // prologue + 256-KiB epilogue, and each launch drags its own ordered-reduce launch.  Grouped, the 108 tiles need only a
 // 2-way M split to give every CU a long block: fewer, longer blocks, a quarter of the slab traffic, one reduce launch.
-constexpr int TG_MAX = 8;
+constexpr int TG_MAX = 16;
 struct TnGroupProb {
   const bf16_t* dY; const bf16_t* X; float* out; float* bias_out; float* dW; float* db;
   size_t split_stride, bias_split_stride;

@@ -186,8 +186,13 @@ def _stack_bwd(g32, g16, stack: _Stack, sh, saved, a: ClipArch, B: int, S: int, 
     C, H = a.hidden, a.heads
     D = C // H
     scale = D ** -0.5
-    for layer, s, sv in zip(reversed(stack.layers), reversed(sh), reversed(saved)):
-        with WgradBatch():   # the layer's six weight gradients leave as ONE grouped launch at the end of the block
+    # weight gradients are deferred (base.WgradBatch) and leave as ONE grouped launch per layer (LC2IS_WGRAD_PAIR=2: per pair of layers, 216 tiles in
+    # 216 full-length blocks without slabs — measured equal to the per-layer form, which holds less memory)
+    pair = int(__import__('os').environ.get('LC2IS_WGRAD_PAIR', '1'))
+    batch, waiting = WgradBatch(), []
+    batch.__enter__()
+    try:
+        for layer, s, sv in zip(reversed(stack.layers), reversed(sh), reversed(saved)):
             x, m1, r1, h, qkv, o, lse, x_mid, m2, r2, h2, z, act = sv
             at, mlp = layer.self_attn, layer.mlp
             # x_out = x_mid + fc2(quick_gelu(fc1(LN2(x_mid))))
@@ -212,8 +217,18 @@ def _stack_bwd(g32, g16, stack: _Stack, sh, saved, a: ClipArch, B: int, S: int, 
             db, _ = vec_grad(layer.layer_norm1.bias)
             g32, g16, _, _ = ops.layernorm_bwd(dh, x, layer.layer_norm1.weight, m1, r1, dres=gm32, dgamma=dg, dbeta=db,
                                                accumulate=accg, need_param_grads=dg is not None)
-        if on_layer_done is not None:      # every gradient of this layer is queued: the DP reducer may start on its slice
-            on_layer_done(layer)
+            waiting.append(layer)
+            if len(waiting) >= pair:
+                batch.flush()
+                if on_layer_done is not None:  # every gradient of these layers is queued: the DP reducer may start on them
+                    for done in waiting:
+                        on_layer_done(done)
+                waiting = []
+    finally:
+        batch.__exit__(None, None, None)     # flushes what is left
+    if on_layer_done is not None:
+        for done in waiting:
+            on_layer_done(done)
     return g32, g16
 
 

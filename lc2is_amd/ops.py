@@ -189,7 +189,7 @@ class TnProblem(C.Structure):
                 ("ldx", C.c_int), ("ldw", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("accumulate", C.c_int)]
 
 
-GROUP_MAX = 8
+GROUP_MAX = 16
 
 
 def gemm_tn_groupable(dy: torch.Tensor, x: torch.Tensor) -> bool:
@@ -200,7 +200,7 @@ def gemm_tn_grouped(problems):
     """problems: list of (dy [M,N] bf16, x [M,K] bf16, dw [N,K] fp32, db [N] fp32 or None, accumulate) with N, K
     multiples of 256 (check with gemm_tn_groupable) — the weight gradients of one layer in one grid."""
     if not 1 <= len(problems) <= GROUP_MAX:
-        raise RuntimeError("lc2is_amd.gemm_tn_grouped: 1..8 problems per launch")
+        raise RuntimeError(f"lc2is_amd.gemm_tn_grouped: 1..{GROUP_MAX} problems per launch")
     arr = (TnProblem * len(problems))()
     for i, (dy, x, dw, db, acc) in enumerate(problems):
         _chk(dy, torch.bfloat16, "dy"); _chk(x, torch.bfloat16, "x"); _chk(dw, torch.float32, "dw"); _chk(db, torch.float32, "db", 1)
