@@ -11,6 +11,9 @@
 
 namespace {
 
+#ifndef LN_BWD_OCC
+#define LN_BWD_OCC 4   // waves per SIMD the backward is compiled for (<= 128 VGPRs): measured against 3
+#endif
 constexpr int LN_MAXV = 8;  // float4 per lane -> C <= 2048 (kernels are instantiated for NV = 1,2,3,4,6,8)
 
 template <int NV>
@@ -84,7 +87,7 @@ __device__ __forceinline__ float4 load_dy4(const bf16_t* dyb, const float* dyf, 
 // grid = nblk blocks of 4 waves; wave w of block b walks rows b*4+w, +4*nblk, ...
 // partial dgamma/dbeta per block -> ws[b][0][C], ws[b][1][C]
 template <int NV>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dyb, int lddy,
+__global__ __launch_bounds__(256, LN_BWD_OCC) void ln_bwd_kernel(const bf16_t* __restrict__ dyb, int lddy,
                                                       const float* __restrict__ dyf, int lddyf,
                                                       const float* __restrict__ x, int ldx,
                                                       const float* __restrict__ gamma,
