@@ -185,12 +185,19 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_ce_kernel(HeadArgs p) {
     }
   }
 
-  if (p.loss_sum && lane == 0 && cnt_acc > 0.f) {
-    atomicAdd(p.loss_sum, loss_acc);
-    atomicAdd(p.loss_sum + 1, cnt_acc);
+  __shared__ float s_red[HEAD_THREADS / 64][2];   // one pair of atomics per block (same-address atomics serialise in L2)
+  if (lane == 0) { s_red[wid][0] = loss_acc; s_red[wid][1] = cnt_acc; }
+  __syncthreads();
+  if (p.loss_sum && tid == 0) {
+    float l = 0.f, c = 0.f;
+#pragma unroll
+    for (int w = 0; w < HEAD_THREADS / 64; ++w) { l += s_red[w][0]; c += s_red[w][1]; }
+    if (c > 0.f) {
+      atomicAdd(p.loss_sum, l);
+      atomicAdd(p.loss_sum + 1, c);
+    }
   }
   if (p.dlo) {
-    __syncthreads();
     for (int i = tid; i < fsize; i += HEAD_THREADS) {
       const int cell = i / Cp, c = i % Cp;
       if (c >= p.C) continue;
@@ -353,12 +360,21 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_ce_s4_kernel(HeadArgs p) {
     }
   }
 
-  if (p.loss_sum && lane == 0 && cnt_acc > 0.f) {
-    atomicAdd(p.loss_sum, loss_acc);
-    atomicAdd(p.loss_sum + 1, cnt_acc);
+  // one pair of atomics per BLOCK: thousands of waves adding to the same two floats serialise in one L2 channel
+  // (that, not the arithmetic, was 80 % of this kernel's time)
+  __shared__ float s_red[HEAD_THREADS / 64][2];
+  if (lane == 0) { s_red[wid][0] = loss_acc; s_red[wid][1] = cnt_acc; }
+  __syncthreads();
+  if (p.loss_sum && tid == 0) {
+    float l = 0.f, c = 0.f;
+#pragma unroll
+    for (int w = 0; w < HEAD_THREADS / 64; ++w) { l += s_red[w][0]; c += s_red[w][1]; }
+    if (c > 0.f) {
+      atomicAdd(p.loss_sum, l);
+      atomicAdd(p.loss_sum + 1, c);
+    }
   }
   if (p.dlo) {
-    __syncthreads();
     for (int i = tid; i < fsize; i += HEAD_THREADS) {
       const int cell = i / Cp, c = i % Cp;
       if (c >= p.C) continue;
