@@ -71,21 +71,23 @@ namespace {
 __global__ __launch_bounds__(1024) void partials_reduce_kernel(const float* __restrict__ ws, int nparts,
                                                                 size_t stride, size_t ws_off_y, int W, float* out0,
                                                                 float* out1, int accumulate) {
-  __shared__ float red[16][64];
-  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cx;
+  // block = 32 columns x 32 row lanes (grid.x = ceil(W / 32)): twice the blocks and half the serial chain of the
+  // 64 x 16 form — these launches sit between the big kernels of the backward and are latency-, not bandwidth-bound
+  __shared__ float red[32][33];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
   float* out = blockIdx.y ? out1 : out0;
   if (!out) return;
   const float* w = ws + blockIdx.y * ws_off_y;
   float s = 0.f;
   if (c < W)
-    for (int k = ry; k < nparts; k += 16) s += w[(size_t)k * stride + c];
+    for (int k = ry; k < nparts; k += 32) s += w[(size_t)k * stride + c];
   red[ry][cx] = s;
   __syncthreads();
   if (ry == 0 && c < W) {
     float t = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) t += red[i][cx];
+    for (int i = 0; i < 32; ++i) t += red[i][cx];
     out[c] = accumulate ? out[c] + t : t;
   }
 }

@@ -695,7 +695,7 @@ extern "C" int lc2is_colsum_bf16(const void* dY, int ldy, float* db, int M, int 
                      ldy, (float*)workspace, M, N);
   int rc = lc2is_check_launch();
   if (rc) return rc;
-  hipLaunchKernelGGL(partials_reduce_kernel, dim3((N + 63) / 64, 1), dim3(1024), 0, stream,
+  hipLaunchKernelGGL(partials_reduce_kernel, dim3((N + 31) / 32, 1), dim3(1024), 0, stream,
                      (const float*)workspace, parts, (size_t)N, (size_t)0, N, db, (float*)nullptr, accumulate);
   return lc2is_check_launch();
 }

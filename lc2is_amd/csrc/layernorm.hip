@@ -243,7 +243,7 @@ extern "C" int lc2is_layernorm_bwd(const void* dy_bf16, int lddy, const float* d
   int rc = lc2is_check_launch();
   if (rc) return rc;
   if (dgamma || dbeta) {
-    hipLaunchKernelGGL(partials_reduce_kernel, dim3((C + 63) / 64, 2), dim3(1024), 0, stream,
+    hipLaunchKernelGGL(partials_reduce_kernel, dim3((C + 31) / 32, 2), dim3(1024), 0, stream,
                        (const float*)workspace, nblk, (size_t)2 * C, (size_t)C, C, dgamma, dbeta, accumulate);
     rc = lc2is_check_launch();
   }
