@@ -542,6 +542,101 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_dma_kernel(Gemm
   gemm_epilogue<TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lane);
 }
 
+// ---- persistent form of the 256x256 LDS-DMA kernel (cfg 11) ---------------------------------------------------------
+// One block per CU walks tiles b, b+G, b+2G, ...  Per tile a K=768 GEMM spends ~13 us in the MFMA loop and nearly as long
+// around it (first-stage DMA latency, epilogue, block launch); here the first K tile of the NEXT output tile is requested
+// before the epilogue of the current one (its stage of LDS is free once the last K step's barrier has passed; the epilogue's
+// LDS patches live in the other stage), the epilogue's non-temporal stores drain under the next tile's MFMA loop, and there
+// is no per-tile block launch.
+template <int ACT>
+__global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtArgs p, int ntiles) {
+  constexpr int BM = 256, BN = 256, WAVES_N = 4, BK = 64;
+  constexpr int WM = 128, WN = 64, TM = 8, TN = 4;
+  constexpr int A_PIECES = 4, W_PIECES = 4;
+  constexpr int STAGE = (BM + BN) * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int lane0 = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+  const int ntn = (p.N + BN - 1) / BN;
+  const unsigned a_bytes = (unsigned)p.M * (unsigned)p.lda * 2u, w_bytes = (unsigned)p.N * (unsigned)p.ldw * 2u;
+  const int nk = p.K / BK;
+
+  // issue the first K tile of output tile `t` into stage 0 (per-lane offsets are temporaries of this call)
+  auto first_stage = [&](int t, int lane) {
+    const int tile = xcd_remap(t, ntiles);
+    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+    const int lrow = lane >> 3, lch = (lane & 7) ^ (lane >> 3);
+    int a_goff[A_PIECES], w_goff[W_PIECES];
+#pragma unroll
+    for (int j = 0; j < A_PIECES; ++j) a_goff[j] = ((m0 + 8 * (wid * A_PIECES + j) + lrow) * p.lda + lch * 8) * 2;
+#pragma unroll
+    for (int j = 0; j < W_PIECES; ++j) w_goff[j] = ((n0 + 8 * (wid * W_PIECES + j) + lrow) * p.ldw + lch * 8) * 2;
+    dma_stage<BM, A_PIECES, W_PIECES>(p.A, a_bytes, p.W, w_bytes, smem, wid, a_goff, w_goff, 0);
+  };
+
+  int t = blockIdx.x;
+  if (t >= ntiles) return;
+  first_stage(t, lane0);
+  for (;;) {
+    // every per-lane constant of the main loop is rebuilt per output tile from a laundered lane id, so nothing but the
+    // accumulators is live across the epilogue (which already sits at the 256-VGPR limit)
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int tile = xcd_remap(t, ntiles);
+    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+    const int lrow = lane >> 3, lch = (lane & 7) ^ (lane >> 3);
+    int a_goff[A_PIECES], w_goff[W_PIECES];
+#pragma unroll
+    for (int j = 0; j < A_PIECES; ++j) a_goff[j] = ((m0 + 8 * (wid * A_PIECES + j) + lrow) * p.lda + lch * 8) * 2;
+#pragma unroll
+    for (int j = 0; j < W_PIECES; ++j) w_goff[j] = ((n0 + 8 * (wid * W_PIECES + j) + lrow) * p.ldw + lch * 8) * 2;
+    const int frow = lane & 15, g = lane >> 4, sw = lane & 7;
+    const int x_frag = (wm * WM + frow) * 128;
+    const int w_frag = BM * 128 + (wn * WN + frow) * 128;
+    const int kc_off0 = ((0 + g) ^ sw) << 4, kc_off1 = ((4 + g) ^ sw) << 4;
+
+    __syncthreads();  // vmcnt(0) + barrier: K tile 0 of this output tile has landed; the previous epilogue's patches are idle
+    f32x4_t acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nk; ++kt) {
+      const char* cur = smem + (kt & 1) * STAGE;
+      if (kt + 1 < nk)
+        dma_stage<BM, A_PIECES, W_PIECES>(p.A, a_bytes, p.W, w_bytes, smem + ((kt + 1) & 1) * STAGE, wid, a_goff, w_goff,
+                                          (kt + 1) * BK * 2);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int ko = ks ? kc_off1 : kc_off0;
+        bf16x8_t xf[TM], wf[TN];
+#pragma unroll
+        for (int j = 0; j < TM; ++j) xf[j] = *(const bf16x8_t*)(cur + x_frag + j * 16 * 128 + ko);
+#pragma unroll
+        for (int i = 0; i < TN; ++i) wf[i] = *(const bf16x8_t*)(cur + w_frag + i * 16 * 128 + ko);
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+    t += gridDim.x;
+    const bool more = t < ntiles;
+    int lane_e = lane0;
+    asm volatile("" : "+v"(lane_e));
+    if (more) first_stage(t, lane_e);   // stage 0 is free (every wave is past the last K step's barrier)
+    if (p.staged_epi)   // one activation variant per kernel instantiation: with all nine inside this loop the allocator spills 600 VGPRs
+      gemm_epilogue_lds_act<ACT, TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lane_e, wid, smem + STAGE);   // patches in stage 1 (+ 9 KiB)
+    else
+      gemm_epilogue_act<ACT, TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lane_e);
+    if (!more) break;
+  }
+}
+
 // ---- ping-pong variant: the two waves of every SIMD alternate LDS-read and MFMA segments ------------------
 // 256x256x64 tile, 8 waves (2x4, 128x64 each).  Waves 0-3 and 4-7 pair up on the four SIMDs; the second group runs
 // one barrier behind the first, so between any two barriers one wave of each SIMD issues its 12 ds_read_b128 (and,
@@ -895,6 +990,36 @@ int launch_dma(const GemmNtArgs& a, hipStream_t stream) {
   return lc2is_check_launch();
 }
 
+template <int ACT>
+int launch_persist_act(const GemmNtArgs& a, hipStream_t stream) {
+  constexpr int LDS = (256 + 256) * 128 + 8 * 64 * 144;   // stage 0 | stage 1 overlaid by the eight epilogue patches (72 KiB)
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm_nt_persist_kernel<ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
+        hipSuccess)
+      return LC2IS_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int ntiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
+  const int grid = ntiles < 256 ? ntiles : 256;
+  hipLaunchKernelGGL(gemm_nt_persist_kernel<ACT>, dim3(grid), dim3(512), LDS, stream, a, ntiles);
+  return lc2is_check_launch();
+}
+
+int launch_persist(const GemmNtArgs& a, hipStream_t stream) {
+  switch (a.act) {
+    case LC2IS_ACT_QUICK_GELU: return launch_persist_act<LC2IS_ACT_QUICK_GELU>(a, stream);
+    case LC2IS_ACT_RELU: return launch_persist_act<LC2IS_ACT_RELU>(a, stream);
+    case LC2IS_ACT_DQUICK_GELU: return launch_persist_act<LC2IS_ACT_DQUICK_GELU>(a, stream);
+    case LC2IS_ACT_DRELU: return launch_persist_act<LC2IS_ACT_DRELU>(a, stream);
+    case LC2IS_ACT_QUICK_GELU_GRAD: return launch_persist_act<LC2IS_ACT_QUICK_GELU_GRAD>(a, stream);
+    case LC2IS_ACT_MUL_AUX: return launch_persist_act<LC2IS_ACT_MUL_AUX>(a, stream);
+    case LC2IS_ACT_GELU_ERF: return launch_persist_act<LC2IS_ACT_GELU_ERF>(a, stream);
+    case LC2IS_ACT_DGELU_ERF: return launch_persist_act<LC2IS_ACT_DGELU_ERF>(a, stream);
+    default: return launch_persist_act<LC2IS_ACT_NONE>(a, stream);
+  }
+}
+
 int launch_ring(const GemmNtArgs& a, hipStream_t stream) {
   constexpr int LDS = 4 * (256 + 256) * 64;
   static bool attr_set = false;
@@ -948,7 +1073,8 @@ int launch_by_cfg(const GemmNtArgs& a, int cfg, hipStream_t stream) {
     case 7: return launch_pp(a, stream);
     case 8: return launch_ring(a, stream);
     case 9: return launch_duo(a, stream);
-    case 10: return launch_dma<128, 384, 2, 4>(a, stream);   // N = 768 / 2304: 3/4-size tiles, 64x96 per wave
+    case 10: return launch_dma<128, 384, 2, 4>(a, stream);
+    case 11: return launch_persist(a, stream);   // N = 768 / 2304: 3/4-size tiles, 64x96 per wave
     // diagnostic ablations of cfg 4 (wrong results by design; tools/gemm_ablate.py only)
     case 41: return launch_dma<256, 256, 2, 4, 1>(a, stream);
     case 42: return launch_dma<256, 256, 2, 4, 2>(a, stream);
