@@ -95,6 +95,7 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dq_kernel(Att
   const int head = blockIdx.y, b = blockIdx.z;
   const int qrow = blockIdx.x * 128 + wid * 32 + l31;
   const bool qok = qrow < p.Sq;
+  const bool wave_active = (int)(blockIdx.x * 128 + wid * 32) < p.Sq;   // wave-uniform
   const float INF = __builtin_inff();
 
   int nkt = (p.Sk + 63) / 64;
@@ -200,6 +201,7 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dq_kernel(Att
     const bool diag = p.causal && (kt * 64 + 63 > blockIdx.x * 128);
     const bool masked = diag || (kt * 64 + 64 > p.Sk) || (p.kbias != nullptr);
 
+    if (wave_active) {   // waves past Sq (ragged last block) only help staging: one wave-uniform branch around the compute
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       f32x16_t st, dpt;
@@ -247,6 +249,7 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dq_kernel(Att
         }
       }
     }
+    }  // wave_active
     if (more) lstore(nxt);
     __syncthreads();
   }
@@ -280,6 +283,7 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(A
   const int head = blockIdx.y, b = blockIdx.z;
   const int kcol = blockIdx.x * 128 + wid * 32 + l31;
   const bool kok = kcol < p.Sk;
+  const bool wave_active = (int)(blockIdx.x * 128 + wid * 32) < p.Sk;   // wave-uniform
   const float INF = __builtin_inff();
 
   const int nqt = (p.Sq + 63) / 64;
@@ -372,6 +376,7 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(A
     const float* delv = lsev + 64;
     const bool diag = p.causal && (blockIdx.x * 128 + 127 > qt * 64);  // some key may exceed some query
 
+    if (wave_active) {   // waves past Sk (ragged last block) only help staging
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       f32x16_t sa, dp;
@@ -423,6 +428,7 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(A
         }
       }
     }
+    }  // wave_active
     if (more) lstore(nxt);
     __syncthreads();
   }

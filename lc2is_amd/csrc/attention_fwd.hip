@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnFwdArgs p) {
   const int head = blockIdx.y, b = blockIdx.z;
   const int q0 = blockIdx.x * 128 + wid * 32;
   const int qrow = q0 + l31;
+  const bool wave_active = q0 < p.Sq;   // wave-uniform (wid comes from threadIdx.x >> 6)
   const float NEG_INF = -__builtin_inff();
 
   int nkt = (p.Sk + 63) / 64;
@@ -146,6 +147,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnFwdArgs p) {
     const bool more = (kt + 1) < nkt;
     if (more) gload(kt + 1);
 
+    // A wave whose 32 query rows all lie past Sq (the ragged last block of S = 1025: three of its four waves) only helps
+    // staging the K/V tiles: one wave-uniform branch around the whole compute segment (branches INSIDE it hurt scheduling).
+    if (wave_active) {
     // ---- S^T = K · Q^T (two 32-key sub-tiles) ----
     f32x16_t st[2];
 #pragma unroll
@@ -241,6 +245,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnFwdArgs p) {
         ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, ot[d], 0, 0, 0);
       }
     }
+    }  // wave_active
 
     if (more) lstore(nxt);
     __syncthreads();
