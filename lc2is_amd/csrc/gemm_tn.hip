@@ -57,7 +57,11 @@ inline TnPlan tn_plan(int M, int N, int K) {
   p.ntk = (K + TN_BK - 1) / TN_BK;
   const int tiles = p.ntn * p.ntk;
   int splits = 1024 / tiles;
-  const int max_splits = (M + 511) / 512;
+  // at least 8 steps of 64 rows per block; once the grid covers the chip twice over (>= 512 blocks) at least 32, so
+  // that a few-tile gradient over hundreds of thousands of rows (Swin stage 1) is not all prologue and slab traffic
+  int max_splits = (M + 511) / 512;
+  const int long_splits = (M + 2047) / 2048;
+  if ((long)tiles * long_splits >= 512) max_splits = long_splits;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   int chunk = (M + splits - 1) / splits;

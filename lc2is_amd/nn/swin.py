@@ -316,6 +316,23 @@ class SwinTransformer(HipModule):
         elif gb is not None:
             ops.colsum(dy16, gb, accumulate=accb)
 
+    @staticmethod
+    def _qkv_wgrad(dqkv16, win16p, at: _Attn, C):
+        """q, k and v share their input: one [3C, Cp] weight-gradient GEMM (+ fused bias gradient), then three slices."""
+        ps = (at.q_proj, at.k_proj, at.v_proj)
+        if not all(l.weight.requires_grad and l.bias.requires_grad for l in ps):
+            for j, lin in enumerate(ps):
+                SwinTransformer._wgrad_padded(dqkv16[:, j * C:(j + 1) * C], win16p, lin.weight, lin.bias, C)
+            return
+        tmp_b = torch.empty(3 * C, dtype=torch.float32, device=dqkv16.device)
+        tmp = ops.gemm_tn(dqkv16, win16p, db=tmp_b)                       # [3C, Cp]
+        for j, lin in enumerate(ps):
+            gw, acc = grad_buf(lin.weight)
+            gb, accb = grad_buf(lin.bias)
+            w, b = tmp[j * C:(j + 1) * C, :C], tmp_b[j * C:(j + 1) * C]
+            gw.add_(w) if acc else gw.copy_(w)
+            gb.add_(b) if accb else gb.copy_(b)
+
     # ---- one block ------------------------------------------------------------------------------------------------------
     def _block_fwd(self, x32, blk: _Block, s, ctx, shift, save):
         a = self.arch
@@ -375,8 +392,7 @@ class SwinTransformer(HipModule):
             gt, acc = grad_buf(table)
             dt = torch.mm(self._onehot, dbias.view(nH, S * S).t())                                # [T, nH], fixed summation order
             gt.add_(dt) if acc else gt.copy_(dt)
-        for j, lin in enumerate((at.q_proj, at.k_proj, at.v_proj)):
-            self._wgrad_padded(dqkv[:, j * C:(j + 1) * C], sv["win16"], lin.weight, lin.bias, C)
+        self._qkv_wgrad(dqkv[:, :3 * C], sv["win16"], at, C)
         dwin16, _, _ = ops.gemm_nt(dqkv, s["wqkvT"][:C], None)                                     # [Mw, C]
         dh16 = ops.rows_gather(dwin16, mp["inv"])                                                 # [M, C] bf16
         dg, accg = vec_grad(blk.layernorm_before.weight)
