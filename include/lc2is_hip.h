@@ -273,6 +273,9 @@ int lc2is_cols_ce(const float* x, const int64_t* labels, float* loss_sum, float*
 /* NPairLoss.forward before its reduction (model/loss.py:30-35): res[i] = sum_p pos_ip / (pos_ip + sum_q neg_iq). */
 int lc2is_npair(const float* x, const float* x_pos, const float* x_neg, float* res, int n, int n_pos, int n_neg, int d,
                 lc2is_stream_t stream);
+/* Its backward: dres [n] = gradient of res; workspace = n * (n_pos + 1) floats.  Fixed summation order. */
+int lc2is_npair_bwd(const float* x, const float* x_pos, const float* x_neg, const float* dres, float* dx, float* dx_pos,
+                    float* dx_neg, float* workspace, int n, int n_pos, int n_neg, int d, lc2is_stream_t stream);
 /* compute_mIOU's confusion counts (metrics.py:82-102): counts[b] = {intersection[K], predicted[K], labelled[K]} (int32,
  * caller-zeroed) from NCHW scores at the upsampled size and the nearest-x S labels. */
 int lc2is_miou_counts(const float* scores_hi, const int64_t* labels_lo, int* counts, int B, int K, int H, int W, int S,

@@ -101,6 +101,61 @@ __global__ __launch_bounds__(256) void npair_kernel(const float* __restrict__ x,
   if (lane == 0) res[row] = acc;
 }
 
+// ---- NPairLoss backward.  res[i] = sum_p pos_ip / (pos_ip + N_i), pos_ip = x_i . xp_p, N_i = x_i . s, s = sum_q xn_q:
+//   d res_i / d pos_ip = N_i / (pos_ip + N_i)^2 =: a_ip,   d res_i / d N_i = -sum_p pos_ip / (pos_ip + N_i)^2 =: b_i.
+// Kernel 1 (wave per row i): dx_i = g_i (sum_p a_ip xp_p + b_i s), and the coefficients A[i][p] = g_i a_ip, Bv[i] = g_i b_i.
+// Kernel 2 (wave per output row, fixed summation order): dxp_p = sum_i A[i][p] x_i;  dxn_q = sum_i Bv[i] x_i for every q.
+__global__ __launch_bounds__(256) void npair_bwd_rows_kernel(const float* __restrict__ x, const float* __restrict__ xp,
+                                                              const float* __restrict__ xn, const float* __restrict__ g,
+                                                              float* dx, float* A, float* Bv, int n, int np, int nn, int d) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const float* xr = x + (size_t)row * d;
+  const float gi = g[row];
+  float negsum = 0.f;
+  for (int j = 0; j < nn; ++j) {
+    float s = 0.f;
+    for (int c = lane; c < d; c += 64) s += xr[c] * xn[(size_t)j * d + c];
+    negsum += wave_sum(s);
+  }
+  float b = 0.f;
+  for (int c = lane; c < d; c += 64) dx[(size_t)row * d + c] = 0.f;
+  for (int j = 0; j < np; ++j) {
+    float s = 0.f;
+    for (int c = lane; c < d; c += 64) s += xr[c] * xp[(size_t)j * d + c];
+    const float pos = wave_sum(s);
+    const float den = pos + negsum;
+    const float a = gi * negsum / (den * den);
+    b -= gi * pos / (den * den);
+    if (lane == 0) A[(size_t)row * np + j] = a;
+    for (int c = lane; c < d; c += 64) dx[(size_t)row * d + c] += a * xp[(size_t)j * d + c];
+  }
+  if (lane == 0) Bv[row] = b;
+  for (int c = lane; c < d; c += 64) {
+    float sn = 0.f;
+    for (int j = 0; j < nn; ++j) sn += xn[(size_t)j * d + c];
+    dx[(size_t)row * d + c] += b * sn;
+  }
+}
+
+__global__ __launch_bounds__(256) void npair_bwd_cols_kernel(const float* __restrict__ x, const float* __restrict__ A,
+                                                              const float* __restrict__ Bv, float* dxp, float* dxn, int n,
+                                                              int np, int nn, int d) {
+  const int lane = threadIdx.x & 63;
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);     // output row: [0, np) -> dxp, np -> the shared dxn row
+  if (o > np) return;
+  for (int c = lane; c < d; c += 64) {
+    float acc = 0.f;
+    for (int i = 0; i < n; ++i) acc += (o < np ? A[(size_t)i * np + o] : Bv[i]) * x[(size_t)i * d + c];
+    if (o < np) {
+      dxp[(size_t)o * d + c] = acc;
+    } else {
+      for (int q = 0; q < nn; ++q) dxn[(size_t)q * d + c] = acc;
+    }
+  }
+}
+
 // ---- mIoU counts: pred = argmax_k scores_hi[b,k,Y,X], label = labels_lo[b, Y/S, X/S] ------------------------
 __global__ __launch_bounds__(256) void miou_counts_kernel(const float* __restrict__ hi, const int64_t* __restrict__ labels,
                                                            int* counts, int B, int K, int H, int W, int S) {
@@ -161,6 +216,23 @@ extern "C" int lc2is_npair(const float* x, const float* x_pos, const float* x_ne
   if (!x || !x_pos || !x_neg || !res) return LC2IS_ERR_NULL;
   if (n <= 0 || n_pos <= 0 || n_neg <= 0 || d <= 0) return LC2IS_ERR_SHAPE;
   hipLaunchKernelGGL(npair_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, x, x_pos, x_neg, res, n, n_pos, n_neg, d);
+  return lc2is_check_launch();
+}
+
+extern "C" int lc2is_npair_bwd(const float* x, const float* x_pos, const float* x_neg, const float* dres, float* dx,
+                               float* dx_pos, float* dx_neg, float* workspace, int n, int n_pos, int n_neg, int d,
+                               lc2is_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!x || !x_pos || !x_neg || !dres || !dx || !dx_pos || !dx_neg || !workspace) return LC2IS_ERR_NULL;
+  if (n <= 0 || n_pos <= 0 || n_neg <= 0 || d <= 0) return LC2IS_ERR_SHAPE;
+  float* A = workspace;                    // [n, n_pos]
+  float* Bv = workspace + (size_t)n * n_pos;  // [n]
+  hipLaunchKernelGGL(npair_bwd_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, x, x_pos, x_neg, dres, dx, A, Bv, n,
+                     n_pos, n_neg, d);
+  int rc = lc2is_check_launch();
+  if (rc) return rc;
+  hipLaunchKernelGGL(npair_bwd_cols_kernel, dim3((n_pos + 1 + 3) / 4), dim3(256), 0, stream, x, (const float*)A,
+                     (const float*)Bv, dx_pos, dx_neg, n, n_pos, n_neg, d);
   return lc2is_check_launch();
 }
 

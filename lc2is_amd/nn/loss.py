@@ -120,8 +120,21 @@ class ContrastiveLoss(nn.Module):
         return _ContrastiveFn.apply(outputs, labels, H)
 
 
+class _NPairFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, x_pos, x_neg):
+        xs = [t.float().contiguous() for t in (x, x_pos, x_neg)]
+        ctx.save_for_backward(*xs)
+        return ops.npair(*xs)
+
+    @staticmethod
+    def backward(ctx, dres):
+        x, xp, xn = ctx.saved_tensors
+        return ops.npair_bwd(x, xp, xn, dres.float().contiguous())
+
+
 class NPairLoss(nn.Module):
-    """Drop-in for model/loss.py:23-37 (forward only on the HIP path; the loss is unused by every composition)."""
+    """Drop-in for model/loss.py:23-37 (forward and backward on the HIP path; unused by every composition)."""
 
     def __init__(self, reduction=torch.mean) -> None:
         super().__init__()
@@ -129,5 +142,5 @@ class NPairLoss(nn.Module):
 
     def forward(self, x: torch.Tensor, x_pos: torch.Tensor, x_neg: torch.Tensor):
         require_cuda(x, "x")
-        res = ops.npair(x.float().contiguous(), x_pos.float().contiguous(), x_neg.float().contiguous())
+        res = _NPairFn.apply(x, x_pos, x_neg)
         return self.reduction(res) if self.reduction else res

@@ -56,6 +56,7 @@ _ARGTYPES = {
     "lc2is_cols_ce": [_P, _P, _P, _P, _F, _I, _I, _I, _I, _P],
     "lc2is_npair": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "lc2is_miou_counts": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "lc2is_npair_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "lc2is_gemm_tn_grouped_workspace_bytes": [_P, _I],
     "lc2is_gemm_tn_grouped": [_P, _I, _P, _Z, _P],
     "lc2is_rows_gather": [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _P],
@@ -621,6 +622,19 @@ def npair(x, x_pos, x_neg):
                                   x_neg.shape[0], x.shape[1], _stream()), "npair")
     return res
 
+
+
+def npair_bwd(x, x_pos, x_neg, dres):
+    """Gradients of npair's res [n] wrt (x, x_pos, x_neg), all fp32."""
+    for t, n in ((x, "x"), (x_pos, "x_pos"), (x_neg, "x_neg")):
+        _dense(t, torch.float32, n)
+    _chk(dres, torch.float32, "dres", 1)
+    n, d = x.shape
+    dx, dxp, dxn = torch.empty_like(x), torch.empty_like(x_pos), torch.empty_like(x_neg)
+    ws = torch.empty(n * (x_pos.shape[0] + 1), dtype=torch.float32, device=x.device)
+    _lib.check(_fn("lc2is_npair_bwd")(_ptr(x), _ptr(x_pos), _ptr(x_neg), _ptr(dres.contiguous()), _ptr(dx), _ptr(dxp), _ptr(dxn),
+                                      _ptr(ws), n, x_pos.shape[0], x_neg.shape[0], d, _stream()), "npair_bwd")
+    return dx, dxp, dxn
 
 def miou_counts(scores_hi, labels_lo, S: int):
     _chk(scores_hi, torch.float32, "scores_hi", 4); _chk(labels_lo, torch.int64, "labels", 3)

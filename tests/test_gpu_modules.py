@@ -201,6 +201,14 @@ def test_contrastive_npair_losses_vs_reference(dev):
     assert _rel(out.grad, x.grad) < 1e-4
     r = N.NPairLoss()(fx["np_x"].to(dev), fx["np_pos"].to(dev), fx["np_neg"].to(dev))
     assert abs(r.item() - fx["npair"].item()) < 1e-4 * max(1.0, abs(fx["npair"].item()))
+    # backward (HIP kernels) against autograd through the oracle's restatement
+    from oracle import ref_cpu as O
+    xs = [fx[k].clone().requires_grad_(True) for k in ("np_x", "np_pos", "np_neg")]
+    O.npair_loss(*xs).backward()
+    ds = [fx[k].to(dev).requires_grad_(True) for k in ("np_x", "np_pos", "np_neg")]
+    N.NPairLoss()(*ds).backward()
+    for a, b in zip(ds, xs):
+        assert _rel(a.grad, b.grad) < 1e-4
 
 
 def test_device_miou_vs_oracle(dev):
