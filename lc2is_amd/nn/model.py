@@ -19,7 +19,7 @@ from torch import nn
 
 from .. import ops
 from .base import HipModule, grad_buf, linear_bwd_params, require_cuda, vec_grad
-from .clip import ClipArch, ImageEncoderCLIP, TextEncoderCLIP
+from .clip import ClipArch, ImageEncoderCLIP, TextEncoderCLIP, TextEncoderCLIPPooler
 from .decoder import DecoderBlock, DecoderLayer
 
 _DATA = Path(__file__).resolve().parent.parent / "data"
@@ -257,3 +257,111 @@ class BaseModelWithText(HipModule):
             outs.append(hi)
         feature_v = torch.cat(outs, dim=1).flatten(2).transpose(1, 2).contiguous()
         return ft16[:K].float(), feature_v, logits
+
+
+class _ContrastiveHeadFn(torch.autograd.Function):
+    """(enc_v [B,P,Cv], enc_t [Nt,Ct]) -> logits [B, (4g)^2, Nt] through the commuted head (scores at the patch grid, then
+    ONE bicubic x4 of the Nt class channels)."""
+
+    @staticmethod
+    def forward(ctx, enc_v, enc_t, model, save):
+        logits, saved = model._head_fwd(enc_v, enc_t, save)
+        ctx.model, ctx.saved = model, saved
+        return logits
+
+    @staticmethod
+    def backward(ctx, gout):
+        dv, dt = ctx.model._head_bwd(gout, ctx.saved)
+        ctx.saved = None
+        return dv, dt, None, None
+
+
+class ContrastiveModel(HipModule):
+    """Drop-in for model/model.py:58-103: CLIP vision tower, POOLED CLIP text tower (one embedding per prompt), TextToPatch,
+    ``logits[b, pixel, prompt] = feature_v @ feature_t^T`` on the bicubically x4-upsampled patch grid.
+
+    ``forward(inputs) -> (feature_t, feature_v, logits)`` like the reference; ``feature_v`` ([B, out^2, out] — the tensor the
+    commuted head exists to avoid) is only materialised when ``return_features`` is True (default False -> ``None``).
+    Trains with ``lc2is_amd.nn.ContrastiveLoss`` (model/loss.py:39-64, which hard-codes 151 prompts)."""
+
+    def __init__(self, patch_size: int = 16, in_size: int = 224, out_size: int = 224, dropout: float = 0, num_layers: int = 1,
+                 *, vision_arch: ClipArch | None = None, text_arch: ClipArch | None = None, out_dim: int = 512) -> None:
+        super().__init__()
+        self.patch_size, self.in_size, self.out_size = patch_size, in_size, out_size
+        if out_size != 4 * (in_size // patch_size):
+            raise ValueError("ContrastiveModel: out_size must be 4 * (in_size // patch_size) (model/model.py:83-86)")
+        self.vision_encoder = ImageEncoderCLIP(in_size=in_size, patch_size=patch_size, arch=vision_arch)
+        self.text_encoder = TextEncoderCLIPPooler(patch_size=patch_size, arch=text_arch)
+        self.pixel_patch = TextToPatch(out=out_dim, img_in=self.vision_encoder.hidden_size(),
+                                       text_in=self.text_encoder.hidden_size())
+        self.return_features = False
+
+    def _params_for_version(self):
+        return []
+
+    def _head_fwd(self, enc_v, enc_t, save):
+        B, P, C = enc_v.shape
+        g = self.in_size // self.patch_size
+        Nt, Ct = enc_t.shape
+        if Nt > KPAD:
+            raise ValueError(f"ContrastiveModel: at most {KPAD} prompts are supported by the fused head")
+        pp = self.pixel_patch
+        psh = pp._ensure_ready()
+        dec16 = ops.cast_bf16(enc_v.reshape(B * P, C).float().contiguous())
+        t16 = torch.zeros(KPAD, Ct, dtype=torch.bfloat16, device=enc_v.device)
+        ops.cast_bf16(enc_t.float().contiguous(), t16[:Nt])
+        ft16, _, _ = ops.gemm_nt(t16, psh["wt"], pp.textual.bias)                   # [KPAD, out]
+        fv16, _, _ = ops.gemm_nt(dec16, psh["wv"], pp.visual.bias)                  # [B*P, out]
+        _, scores, _ = ops.gemm_nt(fv16, ft16, None, out_bf16=None, out_f32=True)   # [B*P, KPAD]
+        _, _, hi = ops.head_upsample_ce(scores, None, B, g, g, Nt, 4, ops.INTERP_BICUBIC, want_scores=True, want_loss=False)
+        logits = hi.flatten(2).transpose(1, 2)                                       # [B, (4g)^2, Nt] (view of NCHW scores)
+        saved = dict(dec16=dec16, t16=t16, ft16=ft16, fv16=fv16, dims=(B, P, C, g, Nt)) if save else None
+        return logits, saved
+
+    def _head_bwd(self, gout, saved):
+        B, P, C, g, Nt = saved["dims"]
+        pp = self.pixel_patch
+        psh = pp._sh
+        gn = gout.transpose(1, 2).reshape(B, Nt, 4 * g, 4 * g).float().contiguous()
+        ds16 = ops.cast_bf16(ops.upsample_bwd_nchw(gn, B, g, g, Nt, 4, ops.INTERP_BICUBIC, KPAD))
+        ft16, fv16, dec16, t16 = saved["ft16"], saved["fv16"], saved["dec16"], saved["t16"]
+        dfv, _, _ = ops.gemm_nt(ds16, ops.transpose_bf16(ft16), None)               # [B*P, out]
+        dft16 = ops.cast_bf16(ops.gemm_tn(ds16, fv16))                               # [KPAD, out]
+        linear_bwd_params(dfv, dec16, pp.visual.weight, pp.visual.bias)
+        _, dv, _ = ops.gemm_nt(dfv, psh["wvT"], None, out_bf16=None, out_f32=True)
+        linear_bwd_params(dft16[:Nt], t16[:Nt], pp.textual.weight, pp.textual.bias)
+        _, dt, _ = ops.gemm_nt(dft16, psh["wtT"], None, out_bf16=None, out_f32=True)   # [KPAD, Ct]
+        pp._grads_ready()
+        return dv.view(B, P, C), dt[:Nt].contiguous()
+
+    def forward(self, inputs: dict):
+        vision_inputs = {k: v for k, v in inputs.items() if k in ["pixel_values"]}
+        text_inputs = {k: v for k, v in inputs.items() if k in ["input_ids", "attention_mask"]}
+        enc_t = self.text_encoder(**text_inputs)                                                # model.py:77
+        enc_v = self.vision_encoder(**vision_inputs)                                            # model.py:80
+        require_cuda(enc_v, "pixel_values")
+        save = torch.is_grad_enabled() and (enc_v.requires_grad or enc_t.requires_grad)
+        logits = _ContrastiveHeadFn.apply(enc_v, enc_t, self, save)
+        feature_t = feature_v = None
+        if self.return_features:
+            with torch.no_grad():
+                feature_t, feature_v = self._features(enc_v, enc_t)
+        return feature_t, feature_v, logits
+
+    def _features(self, enc_v, enc_t):
+        B, P, C = enc_v.shape
+        g = self.in_size // self.patch_size
+        pp = self.pixel_patch
+        psh = pp._ensure_ready()
+        ft16, _, _ = ops.gemm_nt(ops.cast_bf16(enc_t.float().contiguous()), psh["wt"], pp.textual.bias)
+        fv16, _, _ = ops.gemm_nt(ops.cast_bf16(enc_v.reshape(B * P, C).float().contiguous()), psh["wv"], pp.visual.bias)
+        fv = fv16.float()
+        outs = []
+        for c0 in range(0, fv.shape[1], KPAD):   # upsample the visual features 192 channels at a time
+            c1 = min(c0 + KPAD, fv.shape[1])
+            ld = (c1 - c0 + 63) // 64 * 64
+            chunk = torch.zeros(B * P, ld, dtype=torch.float32, device=fv.device)
+            chunk[:, :c1 - c0] = fv[:, c0:c1]
+            _, _, hi = ops.head_upsample_ce(chunk, None, B, g, g, c1 - c0, 4, ops.INTERP_BICUBIC, want_scores=True, want_loss=False)
+            outs.append(hi)
+        return ft16.float(), torch.cat(outs, dim=1).flatten(2).transpose(1, 2).contiguous()

@@ -311,6 +311,20 @@ def base_model_with_text(sd: dict, inputs: dict, cfg: BaseCfg):
     return feature_t, feature_v, logits
 
 
+def contrastive_model(sd: dict, inputs: dict, cfg: BaseCfg):
+    """ContrastiveModel.forward (model/model.py:72-103): vision tower, POOLED text tower (one row per prompt), bicubic x4
+    of the patch grid, TextToPatch, logits = feature_v @ feature_t^T.  Returns (feature_t [Nt,out], feature_v
+    [B,out^2,out], logits [B,out^2,Nt])."""
+    enc_t = text_encoder_clip_pooler(sd, "text_encoder.", inputs["input_ids"], inputs.get("attention_mask"), cfg.text)
+    enc_v = image_encoder_clip(sd, "vision_encoder.", inputs["pixel_values"], cfg.vision)
+    B, P, C = enc_v.shape
+    H = cfg.in_size // cfg.patch
+    x = upsample2d(enc_v.reshape(B, H, H, C).permute(0, 3, 1, 2), scale_factor=4, mode="bicubic")
+    x = x.permute(0, 2, 3, 1).reshape(B, cfg.out_size * cfg.out_size, C)
+    feature_t, feature_v = text_to_patch(sd, "pixel_patch.", x, enc_t)
+    return feature_t, feature_v, feature_v @ feature_t.transpose(0, 1)
+
+
 def train_step_sgd(sd: dict, inputs: dict, labels: Tensor, cfg: BaseCfg, lr: float):
     """One iteration of Engine.train_loop (engine.py:78-104) without aux loss: zero_grad -> forward -> CE
     (mean) -> backward -> SGD step.  Returns (loss, logits, grads dict, new params dict)."""

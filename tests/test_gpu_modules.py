@@ -256,3 +256,42 @@ def test_config4_vit_l14_640_shapes_vs_oracle(dev):
     loss.backward()
     gsum = sum(float(p.grad.abs().sum()) for p in m.parameters() if p.grad is not None)
     assert gsum > 0 and gsum == gsum
+
+
+def test_contrastive_model_vs_reference(dev):
+    """ContrastiveModel (model/model.py:58-103) + ContrastiveLoss against vectors from the reference's own classes."""
+    import lc2is_amd.nn as N
+    from golden_util import make_weights
+    fx = torch.load(G / "contrastive_tiny.pt", weights_only=True)
+    shapes = {k: v.tolist() for k, v in fx["shapes"].items()}
+    m = N.ContrastiveModel(16, 64, 16, vision_arch=N.ClipArch(128, 2, 2, 256),
+                           text_arch=N.ClipArch(64, 1, 2, 128, vocab=512, eos_token_id=511), out_dim=64)
+    named = dict(m.named_parameters())
+    assert {k: list(v.shape) for k, v in named.items()} == shapes
+    w = make_weights(shapes, int(fx["wseed"]))
+    with torch.no_grad():
+        for k, p in named.items():
+            p.copy_(w[k])
+    m = m.to(dev).train()
+    m.return_features = True
+    inputs = dict(pixel_values=fx["pixel_values"].to(dev), input_ids=fx["input_ids"].to(dev))
+    ft, fv, logits = m(inputs)
+    assert logits.shape == fx["logits"].shape
+    assert _rel(logits, fx["logits"]) < 2e-2 and _rel(ft, fx["feature_t"]) < 1e-2 and _rel(fv[:, ::7], fx["feature_v"]) < 2e-2
+    loss, lv, lt = N.ContrastiveLoss()(outputs=logits, labels=fx["labels"].to(dev))
+    close = lambda a, b: abs(a.item() - b.item()) < 2e-2 + 2e-3 * abs(b.item())  # noqa: E731  (losses of ~10-20 here)
+    assert close(loss, fx["loss"]) and close(lv, fx["loss_visual"]) and close(lt, fx["loss_textual"])
+    loss.backward()
+    named = dict(m.named_parameters())
+    worst = max(_rel(named[k].grad, g) for k, g in fx["grad_full"].items())
+    assert worst < 8e-2, worst
+    for k, st in fx["grad_stats"].items():
+        g = named[k].grad
+        ref_abs = float(st[1])
+        if g is None:
+            assert ref_abs == 0.0, k
+            continue
+        if ref_abs < 1e-6 * g.numel():
+            assert float(g.abs().mean()) < 1e-3, k
+            continue
+        assert abs(float(g.abs().sum()) - ref_abs) < 0.1 * ref_abs, (k, float(g.abs().sum()), ref_abs)

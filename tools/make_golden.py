@@ -102,6 +102,58 @@ def make_base_tiny(R):
     print("base_tiny: loss", float(loss), "logits", tuple(logits.shape), "n_grads", len(grads))
 
 
+def make_contrastive(R):
+    """ContrastiveModel (model/model.py:58-103) + ContrastiveLoss (model/loss.py:39-64, 151 classes hard-coded) at tiny
+    dims: forward, loss, backward."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    from golden_util import make_weights
+    torch.manual_seed(1024)
+    vcfg = R["CLIPVisionConfig"](hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                                 image_size=64, patch_size=16)
+    tcfg = R["CLIPTextConfig"](vocab_size=512, hidden_size=64, intermediate_size=128, num_hidden_layers=2,
+                               num_attention_heads=1, max_position_embeddings=77, eos_token_id=511, bos_token_id=510,
+                               pad_token_id=511)
+    m = _bare(R["rmodel"].ContrastiveModel)
+    m.patch_size, m.in_size, m.out_size = 16, 64, 16
+    m.vision_encoder = _bare(R["renc"].ImageEncoderCLIP)
+    m.vision_encoder.in_size, m.vision_encoder.patch_size = 64, 16
+    m.vision_encoder.enc = R["CLIPVisionModel"](vcfg)
+    m.text_encoder = _bare(R["renc"].TextEncoderCLIPPooler)
+    m.text_encoder.patch_size = 16
+    m.text_encoder.enc = R["CLIPTextModel"](tcfg)
+    m.pixel_patch = R["rtp"].TextToPatch(out=64, img_in=128, text_in=64)
+    m.train()
+    params = dict(m.named_parameters())
+    shapes = {k: list(v.shape) for k, v in params.items()}
+    w = make_weights(shapes, 71)
+    with torch.no_grad():
+        for k, p in params.items():
+            p.copy_(w[k])
+    g = torch.Generator().manual_seed(72)
+    B, Nt, L = 2, 151, 8
+    pixel_values = torch.randn(B, 3, 64, 64, generator=g)
+    input_ids = torch.randint(1, 509, (Nt, L), generator=g)
+    input_ids[:, 0] = 510
+    eos = torch.randint(2, L, (Nt,), generator=g)
+    for i in range(Nt):
+        input_ids[i, eos[i]:] = 511
+    labels = torch.randint(0, 151, (B, 16, 16), generator=g)
+    feature_t, feature_v, logits = m(dict(pixel_values=pixel_values, input_ids=input_ids))
+    loss, lv, lt = R["rloss"].ContrastiveLoss()(outputs=logits, labels=labels)
+    loss.backward()
+    keep = [k for k in params if params[k].grad is not None and (k.startswith("pixel_patch.") or "layers.0.self_attn.q_proj.weight" in k
+                                                                  or k.endswith("final_layer_norm.weight") or k.endswith("pre_layrnorm.bias"))]
+    fx = dict(shapes={k: torch.tensor(v) for k, v in shapes.items()}, wseed=torch.tensor(71), pixel_values=pixel_values,
+              input_ids=input_ids, labels=labels, feature_t=feature_t.detach(), feature_v=feature_v.detach()[:, ::7].clone(),
+              logits=logits.detach(), loss=loss.detach(), loss_visual=lv.detach(), loss_textual=lt.detach(),
+              grad_stats={k: (torch.stack([p.grad.sum(), p.grad.abs().sum()]) if p.grad is not None else torch.zeros(2))
+                          for k, p in params.items()},
+              no_grad=torch.tensor([i for i, k in enumerate(params) if params[k].grad is None]),
+              grad_full={k: params[k].grad.clone() for k in keep})
+    torch.save(fx, OUT / "contrastive_tiny.pt")
+    print("contrastive:", tuple(logits.shape), float(loss), "params without grad:", len(fx["no_grad"]))
+
+
 def make_decoder_d96(R):
     """DecoderBlock/DecoderLayer (model/decoder.py:9-21) with head_dim 96, key padding mask, 2 layers."""
     torch.manual_seed(11)
@@ -350,6 +402,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "ftn":
         make_ftn(R)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "contrastive":
+        make_contrastive(R)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "swin":
         make_swin(R)
         return
@@ -359,6 +414,7 @@ def main():
     make_hier(R)
     make_ftn(R)
     make_swin(R)
+    make_contrastive(R)
     # the reference's only data fixture on this path — copied as-is
     protos = torch.load(REF / "model" / "ade20k_prototypes.pt", weights_only=True)
     torch.save(protos.clone(), OUT / "ade20k_prototypes.pt")
