@@ -43,15 +43,31 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
 
+// Wave64 reductions as DPP row ops (quad_perm x2, row_half_mirror, row_mirror), row_bcast:15 / row_bcast:31 into the
+// upper rows and a v_readlane of lane 63: 6 VALU-rate ops and a uniform (SGPR) result.  The __shfl_xor butterfly
+// lowers to six ds_bpermute_b32 (an LDS-pipe round trip each) on gfx950 - tools/probes/wave_reduce.hip.
+// All 64 lanes must be active at the call.
+template <int CTRL, int ROWMASK = 0xf> __device__ __forceinline__ float dpp_or(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
+                                                                CTRL, ROWMASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_or<0xB1>(0.f, v);
+  v += dpp_or<0x4E>(0.f, v);
+  v += dpp_or<0x141>(0.f, v);
+  v += dpp_or<0x140>(0.f, v);
+  v += dpp_or<0x142, 0xa>(0.f, v);
+  v += dpp_or<0x143, 0xc>(0.f, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_or<0xB1>(v, v));
+  v = fmaxf(v, dpp_or<0x4E>(v, v));
+  v = fmaxf(v, dpp_or<0x141>(v, v));
+  v = fmaxf(v, dpp_or<0x140>(v, v));
+  v = fmaxf(v, dpp_or<0x142, 0xa>(v, v));
+  v = fmaxf(v, dpp_or<0x143, 0xc>(v, v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // Bijective XCD-aware remap of a 1-D block id: blocks b and b+8 share an XCD

@@ -177,7 +177,8 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict
     s += (v.x * g.x + v.y * g.y) + (v.z * g.z + v.w * g.w);
   }
   const bool clamped = inv >= (1.f / eps) * 0.999999f;
-  const float dot = clamped ? 0.f : wave_sum(s) * inv * inv;  // <dy, yhat> * inv
+  const float tot = wave_sum(s);
+  const float dot = clamped ? 0.f : tot * inv * inv;  // <dy, yhat> * inv
   for (int c4 = lane; c4 < C4; c4 += 64) {
     const float4 v = xr[c4], g = gr[c4];
     reinterpret_cast<float4*>(dx + (size_t)row * C)[c4] =
