@@ -32,7 +32,8 @@ struct GemmNtArgs {
   float* out_f32; int ldf;
   bf16_t* aux_out; int ldy;
   int M, N, K, act;
-  int staged_epi;  // bf16 epilogue traffic through LDS (needs N % 8 == 0 and 8-element-aligned leading dims)
+  int staged_epi;  // 1: bf16 epilogue traffic through LDS (needs N % 8 == 0 and 8-element-aligned leading dims);
+                   // 2 (host side only, cleared before the launch): fp32-only output through LDS (F32EPI instantiations)
 };
 
 __device__ __forceinline__ float sigmoidf_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }  // v_exp + v_rcp
@@ -316,6 +317,60 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmNtArgs& p, f32x4_t (
 #undef LC2IS_EPI_CALL
 }
 
+// fp32-only outputs (the residual-stream GEMMs: out = resid + A.W^T + bias) through LDS as well: in the MFMA layout a wave
+// store covers 16 rows x 64 B, half a line per row for the fp32 residual read and the fp32 write alike; staged, each wave
+// instruction moves 4 rows x 256 B (whole lines).  64 x 64 fp32 per wave at a 272-byte pitch (conflict-free ds_write_b128 /
+// ds_read_b128).  A lane reads and writes the same addresses, so an in-place residual stays safe.
+template <int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void gemm_epilogue_f32_lds(const GemmNtArgs& p, f32x4_t (&acc)[TN][TM], int m0, int n0, int wm,
+                                                      int wn, int lane, int wid, char* smem) {
+  static_assert(WN == 64 && TM % 4 == 0, "staged epilogue expects 64-column wave tiles");
+  constexpr int PITCH = 272;
+  char* patch = smem + wid * (64 * PITCH);
+  const int frow = lane & 15, g = lane >> 4;
+  const int srow = lane >> 4, sch = lane & 15;   // flush mapping: 4 rows x 16 chunks of 16 B per wave instruction
+  const int nw = n0 + wn * WN;
+  // range-checked buffer accesses (rows >= M and columns >= N fall outside num_records: loads give 0, stores are dropped):
+  // no branches around the 32 loads / 32 stores and one VGPR of offset each (the host keeps M * ld * 4 under 2 GiB)
+  const __amdgpu_buffer_rsrc_t rsR = make_rsrc(p.resid, p.resid ? (unsigned)p.M * (unsigned)p.ldr * 4u : 0u);
+  const __amdgpu_buffer_rsrc_t rsO = make_rsrc(p.out_f32, (unsigned)p.M * (unsigned)p.ldf * 4u);
+  const bool col_ok = (nw + sch * 4) < p.N;
+  f32x4_t bvs[TN];
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int n = nw + i * 16 + g * 4;
+    bvs[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (p.bias && n < p.N) bvs[i] = *(const f32x4_t*)(p.bias + n);
+  }
+#pragma unroll
+  for (int jg = 0; jg < TM / 4; ++jg) {
+    const int mrow0 = m0 + wm * WM + jg * 64;
+    if (mrow0 >= p.M) break;  // wave-uniform
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int jl = 0; jl < 4; ++jl)
+        *(f32x4_t*)(patch + (jl * 16 + frow) * PITCH + (i * 16 + g * 4) * 4) = acc[i][jg * 4 + jl] + bvs[i];
+    const int OOB = 0x7fffffff;
+    const int r_off = col_ok ? ((mrow0 + srow) * p.ldr + nw + sch * 4) * 4 : OOB;
+    const int o_off = col_ok ? ((mrow0 + srow) * p.ldf + nw + sch * 4) * 4 : OOB;
+    const int r_step = p.ldr * 16, o_step = p.ldf * 16;   // 4 rows
+    i32x4_t rv[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) rv[it] = __builtin_amdgcn_raw_buffer_load_b128(rsR, col_ok ? r_off + it * r_step : OOB, 0, 0);
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int q = half * 8 + it;
+        const f32x4_t v = *(const f32x4_t*)(patch + (q * 4 + srow) * PITCH + sch * 16) + __builtin_bit_cast(f32x4_t, rv[it]);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, v), rsO, col_ok ? o_off + q * o_step : OOB, 0, 2);   // nt
+        if (half == 0)   // the second half's row goes out as soon as its register is free
+          rv[it] = __builtin_amdgcn_raw_buffer_load_b128(rsR, col_ok ? r_off + (q + 8) * r_step : OOB, 0, 0);
+      }
+  }
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmNtArgs p) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
@@ -439,7 +494,7 @@ __device__ __forceinline__ void dma_stage(const bf16_t* A, unsigned a_bytes, con
 // it.  256x256 tile, 8 waves (2x4), 128x64 per wave: 12 ds_read_b128 per 32 MFMAs.
 // DBG (diagnostic builds only, tools/gemm_ablate.py; results are WRONG by design): bit 0 = no epilogue,
 // bit 1 = no LDS-DMA inside the K loop (tile 0 is reused), bit 2 = fragments read once before the loop.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int DBG = 0>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int DBG = 0, bool F32EPI = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_dma_kernel(GemmNtArgs p) {
   constexpr int NWAVE = WAVES_M * WAVES_N;
   constexpr int BK = 64;
@@ -533,7 +588,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_dma_kernel(Gemm
     if (sacc == 1.2345e30f && p.out_f32) p.out_f32[0] = sacc;
     return;
   }
-  if constexpr (WN == 64 && TM % 4 == 0) {
+  if constexpr (F32EPI) {   // its own instantiation: with all three epilogues in one kernel the allocator spills 400 VGPRs
+    gemm_epilogue_f32_lds<TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lane, wid, smem);
+    return;
+  } else if constexpr (WN == 64 && TM % 4 == 0) {
     if (p.staged_epi) {
       gemm_epilogue_lds<TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lane, wid, smem);
       return;
@@ -974,11 +1032,12 @@ int launch_cfg(const GemmNtArgs& a, hipStream_t stream) {
   return lc2is_check_launch();
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int DBG = 0>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int DBG = 0, bool F32EPI = false>
 int launch_dma(const GemmNtArgs& a, hipStream_t stream) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
-  constexpr int LDS = 2 * (BM + BN) * 128;
-  auto kern = gemm_nt_dma_kernel<BM, BN, WAVES_M, WAVES_N, DBG>;
+  constexpr int STAGES = 2 * (BM + BN) * 128, PATCHES = F32EPI ? WAVES_M * WAVES_N * 64 * 272 : 0;   // fp32 epilogue patches overlay the stages
+  constexpr int LDS = STAGES > PATCHES ? STAGES : PATCHES;
+  auto kern = gemm_nt_dma_kernel<BM, BN, WAVES_M, WAVES_N, DBG, F32EPI>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
@@ -1062,19 +1121,24 @@ int launch_pp(const GemmNtArgs& a, hipStream_t stream) {
   return lc2is_check_launch();
 }
 
-int launch_by_cfg(const GemmNtArgs& a, int cfg, hipStream_t stream) {
+int launch_by_cfg(const GemmNtArgs& a_in, int cfg, hipStream_t stream) {
+  GemmNtArgs a = a_in;
+  const bool f32_staged = a.staged_epi == 2;
+  if (f32_staged) a.staged_epi = 0;
   switch (cfg) {
     case 1: return launch_cfg<128, 128, 2, 2>(a, stream);
     case 2: return launch_cfg<256, 128, 4, 2>(a, stream);
     case 3: return launch_cfg<64, 64, 2, 2>(a, stream);
-    case 4: return launch_dma<256, 256, 2, 4>(a, stream);
+    case 4: return f32_staged ? launch_dma<256, 256, 2, 4, 0, true>(a, stream) : launch_dma<256, 256, 2, 4>(a, stream);
     case 5: return launch_dma<256, 128, 4, 2>(a, stream);
-    case 6: return launch_dma<128, 128, 2, 2>(a, stream);
+    case 6: return f32_staged ? launch_dma<128, 128, 2, 2, 0, true>(a, stream) : launch_dma<128, 128, 2, 2>(a, stream);
     case 7: return launch_pp(a, stream);
     case 8: return launch_ring(a, stream);
     case 9: return launch_duo(a, stream);
     case 10: return launch_dma<128, 384, 2, 4>(a, stream);
-    case 11: return launch_persist(a, stream);   // N = 768 / 2304: 3/4-size tiles, 64x96 per wave
+    case 11: return launch_persist(a, stream);
+    case 12: return launch_dma<256, 256, 2, 2>(a, stream);      // 4 waves x (128x128): 2/3 of the LDS read traffic per FLOP
+    case 48: return launch_dma<256, 256, 2, 2, 1>(a, stream);   // N = 768 / 2304: 3/4-size tiles, 64x96 per wave
     // diagnostic ablations of cfg 4 (wrong results by design; tools/gemm_ablate.py only)
     case 41: return launch_dma<256, 256, 2, 4, 1>(a, stream);
     case 42: return launch_dma<256, 256, 2, 4, 2>(a, stream);
@@ -1110,6 +1174,10 @@ extern "C" int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw
                (bf16_t*)out_bf16, ldo, out_f32, ldf, (bf16_t*)aux_out, ldy, M, N, K, act, 0};
   a.staged_epi = (N % 8 == 0) && (!out_bf16 || ldo % 8 == 0) && (!aux_out || ldy % 8 == 0) &&
                  (!aux_in || ldx % 8 == 0) && (out_bf16 || aux_out || aux_in);
+  static const bool f32_lds = !(getenv("LC2IS_F32_STAGED") && atoi(getenv("LC2IS_F32_STAGED")) == 0);
+  if (f32_lds && out_f32 && !out_bf16 && !aux_out && !aux_in && act == LC2IS_ACT_NONE &&
+      (double)M * ldf * 4.0 < 2147483648.0 && (!resid || (double)M * ldr * 4.0 < 2147483648.0))
+    a.staged_epi = 2;
   int cfg = tile_cfg;
   if (cfg != 0) return launch_by_cfg(a, cfg, stream);
   const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);

@@ -33,6 +33,38 @@ def test_gemm_nt_plain(dev, M, N, K, cfg):
     assert _rel(ob.float(), ref) < 4e-3  # bf16 output rounding (2^-9 relative)
 
 
+@pytest.mark.parametrize("M,N,K,cfg", [(1025, 768, 768, 4), (300, 196, 128, 4), (515, 328, 192, 6), (4100, 768, 3072, 0),
+                                         (70, 64, 64, 4)])
+@pytest.mark.parametrize("mode", ["resid", "plain", "inplace"])
+def test_gemm_nt_fp32_only_output(dev, M, N, K, cfg, mode):
+    """fp32-only outputs of the LDS-DMA kernels leave through the staged fp32 epilogue (whole-line buffer stores):
+    ragged rows / columns, padded leading dimension, missing residual, residual aliased with the output."""
+    from lc2is_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M * 11 + N + cfg)
+    a = _bf(torch.randn(M, K, generator=g)).to(dev)
+    w = _bf(torch.randn(N, K, generator=g) * 0.05).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    big = torch.full((M + 3, N + 8), 7.0, device=dev)     # guard rows / columns around a strided output view
+    out = big[1:M + 1, 4:N + 4]
+    resid = torch.randn(M, N, generator=g).to(dev)
+    ref = a.double() @ w.double().T + bias.double()
+    if mode == "resid":
+        _, of, _ = ops.gemm_nt(a, w, bias, resid=resid, out_bf16=None, out_f32=out, tile_cfg=cfg)
+        ref = ref + resid.double()
+    elif mode == "inplace":
+        out.copy_(resid)
+        _, of, _ = ops.gemm_nt(a, w, bias, resid=out, out_bf16=None, out_f32=out, tile_cfg=cfg)
+        ref = ref + resid.double()
+    else:
+        _, of, _ = ops.gemm_nt(a, w, bias, out_bf16=None, out_f32=out, tile_cfg=cfg)
+    assert of.data_ptr() == out.data_ptr()
+    assert _rel(of, ref) < 2e-6 * (K ** 0.5)
+    assert (of.double() - ref).abs().max().item() < 1e-3
+    guard = big.clone()
+    guard[1:M + 1, 4:N + 4] = 7.0
+    assert torch.equal(guard, torch.full_like(big, 7.0))    # nothing written outside the view
+
+
 def test_gemm_nt_asymmetric_identity(dev):
     """A = I against an asymmetric W catches a transposed C write (guide §3)."""
     from lc2is_amd import ops

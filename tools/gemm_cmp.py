@@ -20,7 +20,7 @@ for name, N, K, kind in cases:
         if kind == "plain":
             ops.gemm_nt(a, w, bias, out_bf16=outs["o"], tile_cfg=cfg)
         elif kind == "resid":
-            ops.gemm_nt(a, w, bias, resid=outs["r"], out_f32=outs["f"], tile_cfg=cfg)
+            ops.gemm_nt(a, w, bias, resid=outs["r"], out_bf16=None, out_f32=outs["f"], tile_cfg=cfg)
         elif kind == "act":
             ops.gemm_nt(a, w, bias, out_bf16=outs["o"], aux_out=outs["z"], act=ops.ACT_QUICK_GELU, tile_cfg=cfg)
         elif kind == "act5":
