@@ -494,7 +494,8 @@ __device__ __forceinline__ void dma_stage(const bf16_t* A, unsigned a_bytes, con
 // it.  256x256 tile, 8 waves (2x4), 128x64 per wave: 12 ds_read_b128 per 32 MFMAs.
 // DBG (diagnostic builds only, tools/gemm_ablate.py; results are WRONG by design): bit 0 = no epilogue,
 // bit 1 = no LDS-DMA inside the K loop (tile 0 is reused), bit 2 = fragments read once before the loop.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int DBG = 0, bool F32EPI = false>
+// EPI: -1 = epilogue chosen at run time (p.act, p.staged_epi), 0..8 = that activation only, -2 = fp32-only output through LDS
+template <int BM, int BN, int WAVES_M, int WAVES_N, int DBG = 0, int EPI = -1>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_dma_kernel(GemmNtArgs p) {
   constexpr int NWAVE = WAVES_M * WAVES_N;
   constexpr int BK = 64;
@@ -588,8 +589,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_dma_kernel(Gemm
     if (sacc == 1.2345e30f && p.out_f32) p.out_f32[0] = sacc;
     return;
   }
-  if constexpr (F32EPI) {   // its own instantiation: with all three epilogues in one kernel the allocator spills 400 VGPRs
+  if constexpr (EPI == -2) {   // its own instantiation: with all three epilogues in one kernel the allocator spills 400 VGPRs
     gemm_epilogue_f32_lds<TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lane, wid, smem);
+    return;
+  } else if constexpr (EPI >= 0) {   // one activation per instantiation (the run-time switch over all nine costs scratch)
+    if (p.staged_epi)
+      gemm_epilogue_lds_act<EPI, TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lane, wid, smem);
+    else
+      gemm_epilogue_act<EPI, TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lane);
     return;
   } else if constexpr (WN == 64 && TM % 4 == 0) {
     if (p.staged_epi) {
@@ -1032,12 +1039,12 @@ int launch_cfg(const GemmNtArgs& a, hipStream_t stream) {
   return lc2is_check_launch();
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int DBG = 0, bool F32EPI = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int DBG = 0, int EPI = -1>
 int launch_dma(const GemmNtArgs& a, hipStream_t stream) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
-  constexpr int STAGES = 2 * (BM + BN) * 128, PATCHES = F32EPI ? WAVES_M * WAVES_N * 64 * 272 : 0;   // fp32 epilogue patches overlay the stages
+  constexpr int STAGES = 2 * (BM + BN) * 128, PATCHES = EPI == -2 ? WAVES_M * WAVES_N * 64 * 272 : 0;   // fp32 epilogue patches overlay the stages
   constexpr int LDS = STAGES > PATCHES ? STAGES : PATCHES;
-  auto kern = gemm_nt_dma_kernel<BM, BN, WAVES_M, WAVES_N, DBG, F32EPI>;
+  auto kern = gemm_nt_dma_kernel<BM, BN, WAVES_M, WAVES_N, DBG, EPI>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
@@ -1125,13 +1132,26 @@ int launch_by_cfg(const GemmNtArgs& a_in, int cfg, hipStream_t stream) {
   GemmNtArgs a = a_in;
   const bool f32_staged = a.staged_epi == 2;
   if (f32_staged) a.staged_epi = 0;
+  static const bool per_act = !(getenv("LC2IS_GEMM_PER_ACT") && atoi(getenv("LC2IS_GEMM_PER_ACT")) == 0);
   switch (cfg) {
     case 1: return launch_cfg<128, 128, 2, 2>(a, stream);
     case 2: return launch_cfg<256, 128, 4, 2>(a, stream);
     case 3: return launch_cfg<64, 64, 2, 2>(a, stream);
-    case 4: return f32_staged ? launch_dma<256, 256, 2, 4, 0, true>(a, stream) : launch_dma<256, 256, 2, 4>(a, stream);
+    case 4:
+      if (f32_staged) return launch_dma<256, 256, 2, 4, 0, -2>(a, stream);
+      if (!per_act) return launch_dma<256, 256, 2, 4>(a, stream);
+      switch (a.act) {
+        case LC2IS_ACT_QUICK_GELU: return launch_dma<256, 256, 2, 4, 0, LC2IS_ACT_QUICK_GELU>(a, stream);
+        case LC2IS_ACT_RELU: return launch_dma<256, 256, 2, 4, 0, LC2IS_ACT_RELU>(a, stream);
+        case LC2IS_ACT_DQUICK_GELU: return launch_dma<256, 256, 2, 4, 0, LC2IS_ACT_DQUICK_GELU>(a, stream);
+        case LC2IS_ACT_DRELU: return launch_dma<256, 256, 2, 4, 0, LC2IS_ACT_DRELU>(a, stream);
+        case LC2IS_ACT_GELU_ERF: return launch_dma<256, 256, 2, 4, 0, LC2IS_ACT_GELU_ERF>(a, stream);
+        case LC2IS_ACT_DGELU_ERF: return launch_dma<256, 256, 2, 4, 0, LC2IS_ACT_DGELU_ERF>(a, stream);
+        case LC2IS_ACT_NONE: return launch_dma<256, 256, 2, 4, 0, LC2IS_ACT_NONE>(a, stream);
+        default: return launch_dma<256, 256, 2, 4>(a, stream);   // codes 5 / 6 (experiments) keep the run-time switch
+      }
     case 5: return launch_dma<256, 128, 4, 2>(a, stream);
-    case 6: return f32_staged ? launch_dma<128, 128, 2, 2, 0, true>(a, stream) : launch_dma<128, 128, 2, 2>(a, stream);
+    case 6: return f32_staged ? launch_dma<128, 128, 2, 2, 0, -2>(a, stream) : launch_dma<128, 128, 2, 2>(a, stream);
     case 7: return launch_pp(a, stream);
     case 8: return launch_ring(a, stream);
     case 9: return launch_duo(a, stream);
