@@ -19,6 +19,7 @@
 // tile and only applied on tiles that need one.
 #include "common.h"
 #include "lc2is_hip.h"
+#include <cstdlib>
 
 namespace {
 
@@ -52,7 +53,9 @@ __device__ __forceinline__ bf16x8_t tr_frag2(const char* base, int addr_lo, int 
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
-template <int D>
+// DBG (diagnostic builds, LC2IS_ATTN_DBG; results are WRONG by design): bit 0 = no softmax arithmetic, bit 1 = K / V^T fragments
+// read from LDS once before the loop, bit 2 = no global loads / LDS stores inside the loop, bit 3 = no P.V MFMAs
+template <int D, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnFwdArgs p) {
   using Cfg = AttnCfg<D>;
   constexpr int KS = Cfg::KS, VS = Cfg::VS, CH = Cfg::CH, NCH = Cfg::NCH;
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnFwdArgs p) {
     const char* cur = smem + (kt & 1) * Cfg::STAGE;
     char* nxt = smem + ((kt + 1) & 1) * Cfg::STAGE;
     const bool more = (kt + 1) < nkt;
-    if (more) gload(kt + 1);
+    if (more && !(DBG & 4)) gload(kt + 1);
 
     // A wave whose 32 query rows all lie past Sq (the ragged last block of S = 1025: three of its four waves) only helps
     // staging the K/V tiles: one wave-uniform branch around the whole compute segment (branches INSIDE it hurt scheduling).
@@ -158,7 +161,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnFwdArgs p) {
       for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
 #pragma unroll
       for (int s = 0; s < NKS; ++s) {
-        const bf16x8_t kf = *(const bf16x8_t*)(cur + k_frag + 32 * t * KS + 32 * s);
+        bf16x8_t kf = *(const bf16x8_t*)(((DBG & 2) ? smem : cur) + k_frag + 32 * t * KS + 32 * s);
+        if (DBG & 2) { kf = qf[s]; asm volatile("" : "+v"(kf)); }
         st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[t], 0, 0, 0);
       }
     }
@@ -169,7 +173,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnFwdArgs p) {
     const bool diag = p.causal && (kt * 64 + 63 > blockIdx.x * 128);  // some key may exceed some query
     const bool masked = tail || diag || (p.kbias != nullptr);
     float alpha, psum = 0.f;
-    if (!masked) {
+    if (DBG & 1) {
+      alpha = 1.f;
+    } else if (!masked) {
       float mx = st[0][0];
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -241,13 +247,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnFwdArgs p) {
 #pragma unroll
       for (int d = 0; d < NDT; ++d) {
         const int a = v_frag + (32 * t + 16 * s2) * VS + 64 * d;
-        const bf16x8_t vf = tr_frag2(cur + Cfg::KT, a, a + 8 * VS);
-        ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, ot[d], 0, 0, 0);
+        bf16x8_t vf;
+        if (DBG & 2) { vf = qf[d]; asm volatile("" : "+v"(vf)); }
+        else vf = tr_frag2(cur + Cfg::KT, a, a + 8 * VS);
+        if (!(DBG & 8)) ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, ot[d], 0, 0, 0);
+        else ot[d][0] += (float)pf[0] + (float)vf[0];
       }
     }
     }  // wave_active
 
-    if (more) lstore(nxt);
+    if (more && !(DBG & 4)) lstore(nxt);
     __syncthreads();
   }
 
@@ -271,10 +280,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnFwdArgs p) {
   }
 }
 
-template <int D>
+template <int D, int DBG = 0>
 int launch_attn_fwd(const AttnFwdArgs& a, hipStream_t stream) {
   using Cfg = AttnCfg<D>;
-  auto kern = attn_fwd_kernel<D>;
+  auto kern = attn_fwd_kernel<D, DBG>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Cfg::STAGE) !=
@@ -303,7 +312,19 @@ extern "C" int lc2is_attention_fwd(const void* Q, int ldq, const void* K, int ld
   AttnFwdArgs a{(const bf16_t*)Q, ldq, (const bf16_t*)K, ldk, (const bf16_t*)V, ldv, (bf16_t*)O, ldo, lse2,
                 kbias, B, H, Sq, Sk, scale * 1.44269504088896341f, causal};
   switch (D) {
-    case 64: return launch_attn_fwd<64>(a, stream);
+    case 64: {
+      static const int dbg = getenv("LC2IS_ATTN_DBG") ? atoi(getenv("LC2IS_ATTN_DBG")) : 0;
+      switch (dbg) {
+        case 1: return launch_attn_fwd<64, 1>(a, stream);
+        case 2: return launch_attn_fwd<64, 2>(a, stream);
+        case 4: return launch_attn_fwd<64, 4>(a, stream);
+        case 6: return launch_attn_fwd<64, 6>(a, stream);
+        case 7: return launch_attn_fwd<64, 7>(a, stream);
+        case 8: return launch_attn_fwd<64, 8>(a, stream);
+        case 15: return launch_attn_fwd<64, 15>(a, stream);
+        default: return launch_attn_fwd<64>(a, stream);
+      }
+    }
     case 96: return launch_attn_fwd<96>(a, stream);
     case 128: return launch_attn_fwd<128>(a, stream);
     default: return LC2IS_ERR_UNSUPPORTED;

@@ -81,30 +81,40 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 namespace {
-// out[c] (+)= sum_{k < nparts} ws[k*stride + c] for c < W.  Block = 64 columns x 16 row groups (1024 threads):
-// coalesced 256-byte reads, 16-way parallel over the partials, fixed summation order (reproducible).
-// grid.x = ceil(W/64); grid.y selects an (ws, out) pair offset by (y*ws_off, out1 if y==1).
+// out[c] (+)= sum_{k < nparts} ws[k*stride + c] for c < W (W, stride, ws_off_y multiples of 4; ws 16-byte aligned).
+// These launches sit between the big kernels of the backward and are latency-, not bandwidth-bound: block = 32 columns
+// (8 float4 groups) x 128 row lanes, so a thread has at most nparts/128 independent 16-byte loads in flight (8 for the
+// 1024 LayerNorm partials), then a fixed-order 128 -> 32 -> 1 LDS tree (reproducible).  grid.x = ceil(W / 32); grid.y
+// selects an (ws, out) pair offset by (y*ws_off_y, out1 if y==1).
 __global__ __launch_bounds__(1024) void partials_reduce_kernel(const float* __restrict__ ws, int nparts,
                                                                 size_t stride, size_t ws_off_y, int W, float* out0,
                                                                 float* out1, int accumulate) {
-  // block = 32 columns x 32 row lanes (grid.x = ceil(W / 32)): twice the blocks and half the serial chain of the
-  // 64 x 16 form — these launches sit between the big kernels of the backward and are latency-, not bandwidth-bound
-  __shared__ float red[32][33];
-  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cx;
+  __shared__ f32x4_t red[128][8];
+  __shared__ f32x4_t red2[32][8];
+  const int cx = threadIdx.x & 7, ry = threadIdx.x >> 3;
+  const int c = blockIdx.x * 32 + cx * 4;
   float* out = blockIdx.y ? out1 : out0;
   if (!out) return;
   const float* w = ws + blockIdx.y * ws_off_y;
-  float s = 0.f;
-  if (c < W)
-    for (int k = ry; k < nparts; k += 32) s += w[(size_t)k * stride + c];
+  f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+  if (c < W) {
+#pragma unroll 8
+    for (int k = ry; k < nparts; k += 128) s += *(const f32x4_t*)(w + (size_t)k * stride + c);
+  }
   red[ry][cx] = s;
   __syncthreads();
-  if (ry == 0 && c < W) {
-    float t = 0.f;
+  if (threadIdx.x < 256) {
+    const int r2 = threadIdx.x >> 3;
+    red2[r2][cx] = (red[4 * r2][cx] + red[4 * r2 + 1][cx]) + (red[4 * r2 + 2][cx] + red[4 * r2 + 3][cx]);
+  }
+  __syncthreads();
+  if (threadIdx.x < 8 && c < W) {
+    f32x4_t t = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 32; ++i) t += red[i][cx];
-    out[c] = accumulate ? out[c] + t : t;
+    for (int i = 0; i < 32; ++i) t += red2[i][cx];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (c + e < W) out[c + e] = accumulate ? out[c + e] + t[e] : t[e];
   }
 }
 }  // namespace
