@@ -46,6 +46,12 @@ def synth_batch(B, in_size, out_size, L, seed, device):
     return inputs, labels.to(device)
 
 
+_NO_TIMER = bool(os.environ.get("LC2IS_BENCH_NO_GEMM_TIMER"))   # A/B switch: cost of the event pairs themselves
+
+
+SAMPLE_EVERY = 8   # HIP-event pairs around the dominant kernel on every 8th timed step
+
+
 class GemmTimer:
     """HIP-event timing of every call that runs the dominant kernel — gemm_nt_dma_kernel<256,256,2,4>, i.e. the NT GEMMs
     with >= 1024 128x128 tiles of output and N % 256 == 0 (the dispatch rule of lc2is_gemm_nt_bf16) — recorded on the
@@ -57,13 +63,16 @@ class GemmTimer:
         self.ops = ops
         self.records = []
         self._orig = ops.gemm_nt
+        self.active = True      # the event pairs cost ~2 % of the step (A/B 849 vs 832 img/s): bench.py arms them on a
+        self.steps_sampled = 0  # sample of the timed steps (every SAMPLE_EVERY-th), not on all of them
 
     def __enter__(self):
         orig, recs = self._orig, self.records
 
         def timed(a, w, bias=None, **kw):
             M, N = a.shape[0], w.shape[0]
-            if ((M + 127) // 128) * ((N + 127) // 128) < 1024 or N % 256 or kw.get("tile_cfg", 0):
+            if ((M + 127) // 128) * ((N + 127) // 128) < 1024 or N % 256 or kw.get("tile_cfg", 0) or _NO_TIMER \
+                    or not self.active:
                 return orig(a, w, bias, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -189,6 +198,7 @@ def main():
     if use_graph:
         # events cannot be recorded inside a replayed graph: the roofline leg times one eager step instead
         with timer:
+            timer.steps_sampled = 1
             loss = ts.step(inputs, labels)
             sync()
         run = ts.capture(inputs, labels)
@@ -202,11 +212,13 @@ def main():
     else:
         t0 = time.perf_counter()
         with timer:  # every gemm_nt launch of the timed steps is bracketed by HIP events on its launch stream
-            for _ in range(args.steps):
+            for i in range(args.steps):
+                timer.active = (i % SAMPLE_EVERY == 0)
+                timer.steps_sampled += timer.active
                 loss = ts.step(inputs, labels)
             sync()
         dt = time.perf_counter() - t0
-        timed_steps = args.steps
+        timed_steps = timer.steps_sampled
     gsum = timer.summary()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -226,10 +238,11 @@ def main():
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "params_M": round(ts.arena.numel / 1e6, 2)},
             "final_loss": loss_val,
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_dma_kernel<256,256,2,4> (every launch of the timed steps)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_dma_kernel<256,256,2,4> (every launch of each 8th timed step)",
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(args),
                          "launches_per_step": gsum["launches"] / timed_steps, "hip_graph": use_graph,
+                         "event_timed_steps": timed_steps,
                          "avg_launch_us": gsum["seconds"] / max(gsum["launches"], 1) * 1e6,
                          "gemm_nt_time_share": gsum["seconds"] / timed_steps / (dt / args.steps)},
         }
