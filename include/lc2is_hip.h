@@ -77,10 +77,14 @@ int lc2is_gemm_tn_bf16(const void* dY, int ldy, const void* X, int ldx, float* d
                        int N, int K, int accumulate, void* workspace, size_t workspace_bytes,
                        lc2is_stream_t stream);
 
-/* Grouped form: up to 16 weight gradients (one or two transformer layers: q, k, v, out-proj, fc1, fc2 — each the autograd of an
- * nn.Linear call listed above) in ONE grid and one ordered-reduce launch.  Every N and K must be a multiple of 256
+/* Grouped form: up to LC2IS_TN_GROUP_MAX weight gradients (one transformer layer — q, k, v, out-proj, fc1, fc2, each the
+ * autograd of an nn.Linear call listed above — or a whole tower's: 12 layers = 72 problems = 1296 output tiles, scheduled as
+ * full-length blocks plus a few finely split problems that fill the last round of CUs) in ONE grid and one ordered-reduce
+ * launch.  More than 16 problems: the descriptor table is uploaded into the front of the workspace (one small H2D copy on
+ * `stream`; such a call cannot be captured into a hipGraph).  Every N and K must be a multiple of 256
  * (LC2IS_ERR_UNSUPPORTED otherwise: call lc2is_gemm_tn_bf16 per problem).  Same results contract: fp32, bitwise
  * reproducible, db (optional) = column sums of dY, `accumulate` adds to dW / db. */
+#define LC2IS_TN_GROUP_MAX 128
 typedef struct lc2is_tn_problem {
   const void* dY; const void* X; float* dW; float* db;
   int ldy, ldx, ldw, M, N, K, accumulate;

@@ -395,6 +395,29 @@ struct TnGroup {
   TnGroupProb p[TG_MAX];
 };
 
+// More than TG_MAX problems (the weight gradients of a whole tower in one grid): the descriptors live in device memory
+// (front of the workspace, uploaded per call); the block-range ends sit in their own dense arrays so that the search
+// touches a few cache lines.
+constexpr int TG_TBL_MAX = LC2IS_TN_GROUP_MAX;
+struct TnGroupTbl {
+  int n, pad_[3];
+  int blk_end[TG_TBL_MAX];
+  int red_end[TG_TBL_MAX];
+  TnGroupProb p[TG_TBL_MAX];
+};
+constexpr size_t TG_TBL_BYTES = (sizeof(TnGroupTbl) + 255) / 256 * 256;
+
+__global__ __launch_bounds__(512, 2) void gemm_tn_grouped_tbl_kernel(const TnGroupTbl* __restrict__ t) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int i = 0, begin = 0;
+  const int n = t->n;
+#pragma unroll 1
+  while (i < n - 1 && (int)blockIdx.x >= t->blk_end[i]) { begin = t->blk_end[i]; ++i; }
+  const TnGroupProb* q = &t->p[i];
+  tn_dma_body(q->dY, q->ldy, q->X, q->ldx, q->out, q->ldo, q->split_stride, q->bias_out, q->bias_split_stride, q->M, q->N,
+              q->K, q->ntn, q->ntk, q->chunk, q->splits == 1 ? q->accumulate : 0, (int)blockIdx.x - begin, smem);
+}
+
 __global__ __launch_bounds__(512, 2) void gemm_tn_grouped_kernel(TnGroup g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int i = 0, begin = 0;
@@ -405,13 +428,25 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_grouped_kernel(TnGroup g) {
               q.ntk, q.chunk, q.splits == 1 ? q.accumulate : 0, (int)blockIdx.x - begin, smem);
 }
 
+__device__ __forceinline__ void slab_reduce_grouped_body(const TnGroupProb& q, int b);
+
 __global__ __launch_bounds__(256) void slab_reduce_grouped_kernel(TnGroup g) {
   int i = 0, begin = 0;
 #pragma unroll 1
   while (i < g.n - 1 && (int)blockIdx.x >= g.p[i].red_end) { begin = g.p[i].red_end; ++i; }
-  const TnGroupProb& q = g.p[i];
+  slab_reduce_grouped_body(g.p[i], (int)blockIdx.x - begin);
+}
+
+__global__ __launch_bounds__(256) void slab_reduce_grouped_tbl_kernel(const TnGroupTbl* __restrict__ t) {
+  int i = 0, begin = 0;
+  const int n = t->n;
+#pragma unroll 1
+  while (i < n - 1 && (int)blockIdx.x >= t->red_end[i]) { begin = t->red_end[i]; ++i; }
+  slab_reduce_grouped_body(t->p[i], (int)blockIdx.x - begin);
+}
+
+__device__ __forceinline__ void slab_reduce_grouped_body(const TnGroupProb& q, int b) {
   if (q.splits <= 1) return;
-  const int b = (int)blockIdx.x - begin;
   if (b >= q.red_blocks) {                     // fused bias-gradient partials, one column per thread, fixed order
     const int n = (b - q.red_blocks) * 256 + threadIdx.x;
     if (q.db && n < q.N) {
@@ -580,10 +615,14 @@ extern "C" int lc2is_gemm_tn_bf16(const void* dY, int ldy, const void* X, int ld
 
 // ---- grouped weight gradients -------------------------------------------------------------------------------------
 namespace {
-struct TgPlan { int splits; size_t ws_floats; };
+struct TgPlan {
+  int splits[TG_TBL_MAX];   // M-split count per problem
+  int order[TG_TBL_MAX];    // problem indices in grid order (split problems last: their short blocks fill the last round)
+  size_t ws_floats;         // slab floats (after the descriptor table when n > TG_MAX)
+};
 
 inline int tg_valid(const lc2is_tn_problem* pr, int n) {
-  if (!pr || n <= 0 || n > TG_MAX) return LC2IS_ERR_UNSUPPORTED;
+  if (!pr || n <= 0 || n > TG_TBL_MAX) return LC2IS_ERR_UNSUPPORTED;
   for (int i = 0; i < n; ++i) {
     const lc2is_tn_problem& q = pr[i];
     if (!q.dY || !q.X || !q.dW) return LC2IS_ERR_NULL;
@@ -595,14 +634,21 @@ inline int tg_valid(const lc2is_tn_problem* pr, int n) {
   return LC2IS_OK;
 }
 
-// one M-split count for the whole group: minimise  rounds x (longest block + fixed per-block cost)  + slab traffic,
-// in units of one 64-row step of a 256x256 tile (~1.65 us); 13 steps ~ prologue + 256-KiB epilogue of a block.
-inline TgPlan tg_plan(const lc2is_tn_problem* pr, int n) {
+// Cost in units of one 64-row step of a 256x256 tile (~1.65 us); 13 steps ~ prologue + 256-KiB epilogue of a block; one
+// block per CU, so time = rounds x block length.  Two candidate plans:
+//  (uniform) one M-split count for the whole group: rounds x (longest block + 13) + slab traffic — the right shape for a
+//            single layer (108 tiles: 2 splits, 216 blocks in one round);
+//  (tail)    every tile a full-length block except a few small problems that are split so finely that their blocks fill
+//            the last, partly empty round (a whole tower, 1296 tiles: 1278 full blocks in 5 rounds + 18 tiles x 14 splits)
+//            — no slabs for the bulk and ~97 % of the CUs busy instead of 84 %.
+inline void tg_plan(const lc2is_tn_problem* pr, int n, TgPlan& pl) {
   long tiles = 0;
   double wbytes = 0;
   int max_steps = 0, max_splits = 1 << 30;
+  int ptiles[TG_TBL_MAX];
   for (int i = 0; i < n; ++i) {
-    tiles += (long)(pr[i].N / 256) * (pr[i].K / 256);
+    ptiles[i] = (pr[i].N / 256) * (pr[i].K / 256);
+    tiles += ptiles[i];
     wbytes += 4.0 * pr[i].N * pr[i].K;
     const int steps = (pr[i].M + TN_BM - 1) / TN_BM;
     if (steps > max_steps) max_steps = steps;
@@ -611,24 +657,53 @@ inline TgPlan tg_plan(const lc2is_tn_problem* pr, int n) {
   }
   if (max_splits > 32) max_splits = 32;
   if (max_splits < 1) max_splits = 1;
+  const double slab_unit = 2.0 / 4.0e12 / 1.65e-6;   // steps per byte of slab written and read back
   int best = 1;
   double best_t = 1e300;
   for (int sp = 1; sp <= max_splits; ++sp) {
     const long blocks = tiles * sp;
     const double rounds = (double)((blocks + 255) / 256);
-    const double t = rounds * ((max_steps + sp - 1) / sp + 13.0) + (sp > 1 ? sp * wbytes * 2.0 / 4.0e12 / 1.65e-6 : 0.0);
+    const double t = rounds * ((max_steps + sp - 1) / sp + 13.0) + (sp > 1 ? sp * wbytes * slab_unit : 0.0);
     if (t < best_t) { best_t = t; best = sp; }
   }
-  TgPlan pl{best, 0};
-  if (best > 1)
-    for (int i = 0; i < n; ++i) pl.ws_floats += (size_t)best * pr[i].N * ((size_t)pr[i].K + 1);
-  return pl;
+  for (int i = 0; i < n; ++i) { pl.splits[i] = best; pl.order[i] = i; }
+  const int rem = (int)(tiles % 256);
+  if (n > 1 && tiles > 256 && rem != 0 && max_splits >= 2) {
+    bool in_tail[TG_TBL_MAX] = {};
+    int ts = 0;
+    double tail_bytes = 0;
+    while (ts < rem) {   // smallest problems first (later index on ties)
+      int pick = -1;
+      for (int i = 0; i < n; ++i)
+        if (!in_tail[i] && (pick < 0 || ptiles[i] <= ptiles[pick])) pick = i;
+      if (pick < 0) break;
+      in_tail[pick] = true;
+      ts += ptiles[pick];
+      tail_bytes += 4.0 * pr[pick].N * pr[pick].K;
+    }
+    int sp = ts > 0 ? 256 / ts : 0;
+    if (sp > max_splits) sp = max_splits;
+    if (ts >= rem && sp >= 2) {
+      const double rounds = (double)((tiles - ts + 255) / 256);
+      const double t = rounds * (max_steps + 13.0) + ((max_steps + sp - 1) / sp + 13.0) + sp * tail_bytes * slab_unit;
+      if (t < best_t) {
+        int k = 0;
+        for (int i = 0; i < n; ++i) if (!in_tail[i]) { pl.order[k++] = i; pl.splits[i] = 1; }
+        for (int i = 0; i < n; ++i) if (in_tail[i]) { pl.order[k++] = i; pl.splits[i] = sp; }
+      }
+    }
+  }
+  pl.ws_floats = 0;
+  for (int i = 0; i < n; ++i)
+    if (pl.splits[i] > 1) pl.ws_floats += (size_t)pl.splits[i] * pr[i].N * ((size_t)pr[i].K + 1);
 }
 }  // namespace
 
 extern "C" size_t lc2is_gemm_tn_grouped_workspace_bytes(const lc2is_tn_problem* problems, int n) {
   if (tg_valid(problems, n) != LC2IS_OK) return 0;
-  return tg_plan(problems, n).ws_floats * sizeof(float);
+  TgPlan pl;
+  tg_plan(problems, n, pl);
+  return pl.ws_floats * sizeof(float) + (n > TG_MAX ? TG_TBL_BYTES : 0);
 }
 
 extern "C" int lc2is_gemm_tn_grouped(const lc2is_tn_problem* problems, int n, void* workspace, size_t workspace_bytes,
@@ -636,28 +711,37 @@ extern "C" int lc2is_gemm_tn_grouped(const lc2is_tn_problem* problems, int n, vo
   hipStream_t stream = (hipStream_t)stream_;
   int rc = tg_valid(problems, n);
   if (rc) return rc;
-  const TgPlan pl = tg_plan(problems, n);
-  if (pl.ws_floats && (!workspace || workspace_bytes < pl.ws_floats * sizeof(float))) return LC2IS_ERR_WORKSPACE;
-  TnGroup g{};
-  g.n = n;
-  float* ws = (float*)workspace;
+  TgPlan pl;
+  tg_plan(problems, n, pl);
+  const bool tbl = n > TG_MAX;
+  const size_t need = pl.ws_floats * sizeof(float) + (tbl ? TG_TBL_BYTES : 0);
+  if (need && (!workspace || workspace_bytes < need)) return LC2IS_ERR_WORKSPACE;
+  static thread_local TnGroupTbl ring[4];   // host image of the table (hipMemcpyAsync stages pageable memory before it
+  static thread_local unsigned ring_pos = 0;  // returns; the ring is slack on top of that)
+  TnGroupTbl& t = ring[ring_pos++ & 3];
+  t.n = n;
+  float* ws = (float*)((char*)workspace + (tbl ? TG_TBL_BYTES : 0));
   int blk = 0, red = 0;
-  for (int i = 0; i < n; ++i) {
+  for (int k = 0; k < n; ++k) {
+    const int i = pl.order[k];
     const lc2is_tn_problem& q = problems[i];
-    TnGroupProb& d = g.p[i];
+    TnGroupProb& d = t.p[k];
     d.dY = (const bf16_t*)q.dY; d.X = (const bf16_t*)q.X; d.dW = q.dW; d.db = q.db;
     d.ldy = q.ldy; d.ldx = q.ldx; d.ldw = q.ldw; d.M = q.M; d.N = q.N; d.K = q.K; d.accumulate = q.accumulate;
     d.ntn = q.N / 256; d.ntk = q.K / 256;
-    int chunk = (q.M + pl.splits - 1) / pl.splits;
+    int chunk = (q.M + pl.splits[i] - 1) / pl.splits[i];
     chunk = (chunk + TN_BM - 1) / TN_BM * TN_BM;
     d.chunk = chunk;
     d.splits = (q.M + chunk - 1) / chunk;
-    if (d.splits > 1) {
-      d.out = ws; d.ldo = q.K; d.split_stride = (size_t)q.N * q.K;
-      ws += (size_t)d.splits * q.N * q.K;
-      d.bias_out = q.db ? ws : nullptr; d.bias_split_stride = (size_t)q.N;
-      ws += (size_t)d.splits * q.N;
-    } else {
+    if (pl.splits[i] > 1) {   // (slab space is reserved for the planned count even if the rounded chunk needs fewer)
+      float* base = ws;
+      ws += (size_t)pl.splits[i] * q.N * ((size_t)q.K + 1);
+      if (d.splits > 1) {
+        d.out = base; d.ldo = q.K; d.split_stride = (size_t)q.N * q.K;
+        d.bias_out = q.db ? base + (size_t)d.splits * q.N * q.K : nullptr; d.bias_split_stride = (size_t)q.N;
+      }
+    }
+    if (d.splits <= 1) {
       d.out = q.dW; d.ldo = q.ldw; d.split_stride = 0; d.bias_out = q.db; d.bias_split_stride = 0;
     }
     blk += d.ntn * d.ntk * d.splits;
@@ -668,14 +752,31 @@ extern "C" int lc2is_gemm_tn_grouped(const lc2is_tn_problem* problems, int n, vo
     d.red_blocks = d.splits > 1 ? rb : 0;
     red += d.splits > 1 ? rb + (q.db ? (q.N + 255) / 256 : 0) : 0;
     d.red_end = red;
+    t.blk_end[k] = blk;
+    t.red_end[k] = red;
   }
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)gemm_tn_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            2 * TD_STAGE) != hipSuccess ||
+        hipFuncSetAttribute((const void*)gemm_tn_grouped_tbl_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             2 * TD_STAGE) != hipSuccess)
       return LC2IS_ERR_LAUNCH;
     attr_set = true;
   }
+  if (tbl) {
+    if (hipMemcpyAsync(workspace, &t, sizeof(TnGroupTbl), hipMemcpyHostToDevice, stream) != hipSuccess)
+      return LC2IS_ERR_LAUNCH;
+    const TnGroupTbl* dt = (const TnGroupTbl*)workspace;
+    hipLaunchKernelGGL(gemm_tn_grouped_tbl_kernel, dim3(blk), dim3(512), 2 * TD_STAGE, stream, dt);
+    rc = lc2is_check_launch();
+    if (rc || red == 0) return rc;
+    hipLaunchKernelGGL(slab_reduce_grouped_tbl_kernel, dim3(red), dim3(256), 0, stream, dt);
+    return lc2is_check_launch();
+  }
+  TnGroup g{};
+  g.n = n;
+  for (int k = 0; k < n; ++k) g.p[k] = t.p[k];
   hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(blk), dim3(512), 2 * TD_STAGE, stream, g);
   rc = lc2is_check_launch();
   if (rc || red == 0) return rc;

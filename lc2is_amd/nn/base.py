@@ -172,8 +172,9 @@ class WgradBatch:
 
     def flush(self):
         items, self.items = self.items, []
-        for i in range(0, len(items), ops.GROUP_MAX):
-            chunk = items[i:i + ops.GROUP_MAX]
+        gmax = ops.GROUP_MAX_CAPTURABLE if torch.cuda.is_current_stream_capturing() else ops.GROUP_MAX
+        for i in range(0, len(items), gmax):
+            chunk = items[i:i + gmax]
             if len(chunk) == 1:
                 dy, x, g, gb, acc = chunk[0]
                 ops.gemm_tn(dy, x, g, accumulate=acc, db=gb)

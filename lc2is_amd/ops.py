@@ -190,7 +190,8 @@ class TnProblem(C.Structure):
                 ("ldx", C.c_int), ("ldw", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("accumulate", C.c_int)]
 
 
-GROUP_MAX = 16
+GROUP_MAX = 128        # LC2IS_TN_GROUP_MAX
+GROUP_MAX_CAPTURABLE = 16   # above this the call uploads its descriptor table (H2D copy): not hipGraph-capturable
 
 
 def gemm_tn_groupable(dy: torch.Tensor, x: torch.Tensor) -> bool:
@@ -199,7 +200,7 @@ def gemm_tn_groupable(dy: torch.Tensor, x: torch.Tensor) -> bool:
 
 def gemm_tn_grouped(problems):
     """problems: list of (dy [M,N] bf16, x [M,K] bf16, dw [N,K] fp32, db [N] fp32 or None, accumulate) with N, K
-    multiples of 256 (check with gemm_tn_groupable) — the weight gradients of one layer in one grid."""
+    multiples of 256 (check with gemm_tn_groupable) — the weight gradients of one layer, or of a whole tower, in one grid."""
     if not 1 <= len(problems) <= GROUP_MAX:
         raise RuntimeError(f"lc2is_amd.gemm_tn_grouped: 1..{GROUP_MAX} problems per launch")
     arr = (TnProblem * len(problems))()

@@ -274,3 +274,36 @@ def test_gemm_tn_grouped(dev):
         assert torch.equal(a[2], b[2]) and (a[3] is None or torch.equal(a[3], b[3]))   # bitwise reproducible
     with pytest.raises(RuntimeError):
         ops.gemm_tn_grouped([(probs[0][0][:, :200], probs[0][1], torch.empty(200, 768, device=dev), None, False)] * 2)
+
+
+def test_gemm_tn_grouped_whole_tower_table_and_tail_split(dev):
+    """More than 16 problems go through the device-side descriptor table; with > 256 output tiles and a ragged last round
+    the planner keeps the bulk as full-length blocks and splits the smallest problems (slabs + ordered reduce for those
+    only).  59 problems x (1..6 tiles) = 297 tiles, 41 past one round: the smallest problems are split, the rest run full length."""
+    from lc2is_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(23)
+    M = 4160
+    x_by_k = {K: _bf(torch.randn(M, K, generator=g)).to(dev) for K in (256, 512, 768)}
+    shapes = [(256, 256)] * 5 + [(256, 512)] * 4 + [(512, 256)] * 4 + [(768, 256)] * 4 + [(512, 512)] * 3 + \
+             [(512, 768)] * 3 + [(768, 512)] * 36
+    assert len(shapes) > 16 and sum((n // 256) * (k // 256) for n, k in shapes) > 256
+    probs, refs = [], []
+    for i, (N, K) in enumerate(shapes):
+        dy = _bf(torch.randn(M, N, generator=g)).to(dev)
+        x = x_by_k[K]
+        acc = i % 3 == 1
+        dw = torch.full((N, K), 2.0, device=dev)
+        db = torch.full((N,), 3.0, device=dev) if i % 4 != 2 else None
+        probs.append((dy, x, dw, db, acc))
+        refs.append((dy.double().T @ x.double() + (2.0 if acc else 0.0), dy.double().sum(0) + (3.0 if acc else 0.0)))
+    ops.gemm_tn_grouped(probs)
+    for (dy, x, dw, db, acc), (rw, rb) in zip(probs, refs):
+        assert _rel(dw, rw) < 1e-5
+        if db is not None:
+            assert _rel(db, rb) < 1e-5
+    again = [(dy, x, torch.full_like(dw, 2.0), None if db is None else torch.full_like(db, 3.0), acc) for dy, x, dw, db, acc in probs]
+    ops.gemm_tn_grouped(again)
+    for a, b in zip(again, probs):
+        assert torch.equal(a[2], b[2]) and (a[3] is None or torch.equal(a[3], b[3]))   # bitwise reproducible
+    with pytest.raises(RuntimeError):
+        ops.gemm_tn_grouped(probs * 3)      # 177 problems > LC2IS_TN_GROUP_MAX
