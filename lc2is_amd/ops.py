@@ -8,6 +8,7 @@ allocator, nothing else).  There is no CPU path: a non-CUDA tensor is an error.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -194,8 +195,13 @@ GROUP_MAX = 128        # LC2IS_TN_GROUP_MAX
 GROUP_MAX_CAPTURABLE = 16   # above this the call uploads its descriptor table (H2D copy): not hipGraph-capturable
 
 
+# rows (tokens) from which a weight gradient joins a grouped launch: the text tower (151 prompts x 16 tokens = 2416 rows, 72
+# problems of 4..16 tiles) stays 76 small launches on its side stream: grouping them (1024) measured neutral on the step
+_GROUP_MIN_ROWS = int(os.environ.get("LC2IS_GROUP_MIN_ROWS", "4096"))
+
+
 def gemm_tn_groupable(dy: torch.Tensor, x: torch.Tensor) -> bool:
-    return dy.shape[1] % 256 == 0 and x.shape[1] % 256 == 0 and dy.shape[0] >= 4096
+    return dy.shape[1] % 256 == 0 and x.shape[1] % 256 == 0 and dy.shape[0] >= _GROUP_MIN_ROWS
 
 
 def gemm_tn_grouped(problems):
