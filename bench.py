@@ -49,7 +49,7 @@ def synth_batch(B, in_size, out_size, L, seed, device):
 _NO_TIMER = bool(os.environ.get("LC2IS_BENCH_NO_GEMM_TIMER"))   # A/B switch: cost of the event pairs themselves
 
 
-SAMPLE_EVERY = 8   # HIP-event pairs around the dominant kernel on every 8th timed step
+SAMPLE_EVERY = 4   # HIP-event pairs around the dominant kernel on every 4th timed step
 
 
 class GemmTimer:
@@ -238,7 +238,7 @@ def main():
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "params_M": round(ts.arena.numel / 1e6, 2)},
             "final_loss": loss_val,
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_dma_kernel<256,256,2,4> (every launch of each 8th timed step)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_dma_kernel<256,256,2,4> (every launch of each 4th timed step)",
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(args),
                          "launches_per_step": gsum["launches"] / timed_steps, "hip_graph": use_graph,
