@@ -291,7 +291,9 @@ int launch_attn_fwd(const AttnFwdArgs& a, hipStream_t stream) {
       return LC2IS_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((a.Sq + 127) / 128, a.H, a.B), dim3(256), 2 * Cfg::STAGE, stream, a);
+  static const int lds_pad = getenv("LC2IS_ATTN_LDS_PAD") ? atoi(getenv("LC2IS_ATTN_LDS_PAD")) : 0;   // occupancy probe (tools/attn_ablate.py)
+  if (lds_pad) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Cfg::STAGE + lds_pad);
+  hipLaunchKernelGGL(kern, dim3((a.Sq + 127) / 128, a.H, a.B), dim3(256), 2 * Cfg::STAGE + lds_pad, stream, a);
   return lc2is_check_launch();
 }
 
