@@ -14,6 +14,7 @@
 //   VALU; the GEMMs of the blocks run on the shared MFMA kernels.
 #include "common.h"
 #include "lc2is_hip.h"
+#include <cstdlib>
 
 namespace {
 
@@ -273,6 +274,198 @@ __global__ __launch_bounds__(64) void swin_attn_bwd_kernel(SwinAttnArgs a) {
   }
 }
 
+// ---- backward on the matrix cores ------------------------------------------------------------------------------------
+// Same block structure (one wave per block, block (h, chunk) walks its windows in order, dS accumulated per block in LDS), but
+// the five products of a (window, head) are 40 v_mfma_f32_32x32x16_bf16 instead of ~10^4 VALU FMAs fed by LDS broadcasts:
+//   S[q][key] = Q.K^T and dP[q][key] = dO.V^T   with the row fragments loaded straight from global memory (rows padded to 64
+//               with zeros), result tiles "key on the lane, query rows in the registers";
+//   P = exp(S*scale + bias (+ mask) - lse), dS = P o (dP - delta) elementwise on those registers; dS also goes to LDS (bf16);
+//   dV[key][d] = P^T.dO and dK[key][d] = dS^T.Q  take the P / dS accumulator registers directly as the MFMA A operand
+//               (accumulator-as-operand: lane = key = A row, registers = the 16 queries of a k step, in the order
+//               q0+{0..3}, q0+8+{0..3} with q0 = 32tq + 16s2 + 4hh) against dO^T / Q^T images in LDS read in that same order;
+//   dQ[q][d]   = dS.K from the dS image (rows q) and the K^T image.
+// LDS images are bf16 with a 144-byte row pitch (128 B of data + 16: conflict-free ds_read_b128 over 32 rows).
+constexpr int SWM_P = 144;
+
+__device__ __forceinline__ bf16x8_t swm_pack8(const f32x16_t& v, int base) {
+  bf16x8_t r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (__bf16)v[base + j];
+  return r;
+}
+
+__device__ __forceinline__ float swm_dot8(const bf16x8_t& a, const bf16x8_t& b) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += (float)a[i] * (float)b[i];
+  return s;
+}
+
+__global__ __launch_bounds__(64) void swin_attn_bwd_mfma_kernel(SwinAttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x, l31 = lane & 31, hh = lane >> 5;
+  const int S = a.ws * a.ws;
+  const int h = blockIdx.x % a.nH, chunk = blockIdx.x / a.nH;
+  char* QT = smem;                          // [32 d][SWM_P]  Q^T
+  char* KT = QT + 32 * SWM_P;               //                K^T
+  char* GT = KT + 32 * SWM_P;               //                dO^T
+  char* DS = GT + 32 * SWM_P;               // [64 q][SWM_P]  dS
+  float* Ls = (float*)(DS + 64 * SWM_P);    // [64] lse (+inf on the padding rows)
+  float* Dp = Ls + 64;                      // [2][64] the two half-row partials of delta = dO . O
+  int* Rid = (int*)(Dp + 128);              // [64] cyclic-shift region of each token of the window
+  float* Acc = (float*)(Rid + 64);          // [S][S] bias-gradient accumulator of this block
+  for (int idx = lane; idx < S * S; idx += 64) Acc[idx] = 0.f;
+  const int w_begin = chunk * a.chunk;
+  int w_end = w_begin + a.chunk;
+  if (w_end > a.nwin) w_end = a.nwin;
+  const float INF = __builtin_inff();
+  const bf16x8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  const char* bias_h = (const char*)(a.bias + (size_t)h * S * S);
+  for (int win = w_begin; win < w_end; ++win) {
+    // (the per-lane offsets below do not depend on the window; computed outside the loop they would pin ~100 VGPRs, so an
+    //  opaque zero ties them to the iteration)
+    int opq = 0;
+    asm volatile("" : "+v"(opq));
+    const int hh_o = hh + opq, l31_o = l31 + opq;
+    // ---- row fragments: tile t = rows 32t + l31, k step s = columns 16s + 8hh .. +7 of the head ----
+    bf16x8_t qf[2][2], kf[2][2], vf[2][2], gf[2][2];
+    float dpart[2] = {0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int r = 32 * t + l31;
+      const bool ok = r < S;
+      const size_t row = (size_t)win * S + (ok ? r : 0);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int col = h * SW_D + 16 * s2 + 8 * hh;
+        qf[t][s2] = ok ? *(const bf16x8_t*)(a.qkv + row * a.ld + col) : zero8;
+        kf[t][s2] = ok ? *(const bf16x8_t*)(a.qkv + row * a.ld + a.C + col) : zero8;
+        vf[t][s2] = ok ? *(const bf16x8_t*)(a.qkv + row * a.ld + 2 * a.C + col) : zero8;
+        gf[t][s2] = ok ? *(const bf16x8_t*)(a.dout + row * a.lddo + col) : zero8;
+        const bf16x8_t of = ok ? *(const bf16x8_t*)(a.o + row * a.ld_o + col) : zero8;
+        dpart[t] += swm_dot8(gf[t][s2], of);
+      }
+    }
+    const float lse_l = lane < S ? a.lse[((size_t)win * a.nH + h) * S + lane] : INF;
+    const int widx = win % a.win_per_img, wy = widx / a.nwx, wx = widx % a.nwx;
+    int rid_l = -1;
+    if (lane < S && a.shift > 0)
+      rid_l = sw_region(wy * a.ws + lane / a.ws, a.Hp, a.ws, a.shift) * 3 + sw_region(wx * a.ws + lane % a.ws, a.Wp, a.ws, a.shift);
+    SW_LDS_SYNC();   // the previous window is done with the images
+    Ls[lane] = lse_l;
+    Rid[lane] = rid_l;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      Dp[hh * 64 + 32 * t + l31] = dpart[t];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int off = (16 * s2 + 8 * hh + e) * SWM_P + (32 * t + l31) * 2;
+          *(__bf16*)(QT + off) = qf[t][s2][e];
+          *(__bf16*)(KT + off) = kf[t][s2][e];
+          *(__bf16*)(GT + off) = gf[t][s2][e];
+        }
+    }
+    SW_LDS_SYNC();
+    int rid_key[2];
+    rid_key[0] = Rid[l31];
+    rid_key[1] = Rid[32 + l31];
+    f32x16_t dv[2], dk[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dv[t][r] = 0.f; dk[t][r] = 0.f; }
+#pragma unroll
+    for (int tq = 0; tq < 2; ++tq) {
+      f32x16_t sa[2], dp[2];
+#pragma unroll
+      for (int tk = 0; tk < 2; ++tk) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sa[tk][r] = 0.f; dp[tk][r] = 0.f; }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          sa[tk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[tq][s2], kf[tk][s2], sa[tk], 0, 0, 0);
+          dp[tk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[tq][s2], vf[tk][s2], dp[tk], 0, 0, 0);
+        }
+      }
+      // ---- P, dS on the accumulator registers: register r = query row 32tq + 8(r>>2) + 4hh + (r&3), lane = key.
+      // Branch-free: padding rows / columns read a clamped bias entry, get p = 0 and add their zero into a per-lane dummy
+      // slot behind the accumulator (never two lanes on one LDS word). ----
+      const int keyc0 = l31_o < S ? l31_o : S - 1, keyc1 = 32 + l31_o < S ? 32 + l31_o : S - 1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int q = 32 * tq + 8 * (r >> 2) + (r & 3) + 4 * hh_o;
+        const bool q_ok = q < S;
+        const int qc = q_ok ? q : S - 1;
+        const float lse_q = Ls[q];
+        const float del_q = Dp[q] + Dp[64 + q];
+        const int rid_q = Rid[q];
+#pragma unroll
+        for (int tk = 0; tk < 2; ++tk) {
+          const int key = 32 * tk + l31_o;
+          const bool valid = q_ok && key < S;
+          const float bz = *(const float*)(bias_h + (unsigned)((qc * S + (tk ? keyc1 : keyc0)) * 4));
+          float sc = sa[tk][r] * a.scale + bz;
+          sc += (a.shift > 0 && rid_q != rid_key[tk]) ? -100.0f : 0.f;
+          const float p = valid ? __expf(sc - lse_q) : 0.f;   // (lse = +inf on padding rows: exp(-inf) = 0 as well)
+          const float ds = p * (dp[tk][r] - del_q);
+          float* slot = Acc + (valid ? q * S + key : S * S + lane);
+          *slot += ds;
+          sa[tk][r] = p;
+          dp[tk][r] = ds;
+          *(__bf16*)(DS + q * SWM_P + key * 2) = (__bf16)ds;
+        }
+      }
+      // ---- dV += P^T.dO, dK += dS^T.Q over this tile of 32 queries ----
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int q0 = 32 * tq + 16 * s2 + 4 * hh;
+        const s16x4_t g0 = *(const s16x4_t*)(GT + l31 * SWM_P + q0 * 2), g1 = *(const s16x4_t*)(GT + l31 * SWM_P + (q0 + 8) * 2);
+        const s16x4_t x0 = *(const s16x4_t*)(QT + l31 * SWM_P + q0 * 2), x1 = *(const s16x4_t*)(QT + l31 * SWM_P + (q0 + 8) * 2);
+        const s16x8_t gv = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+        const s16x8_t xv = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+        const bf16x8_t gB = __builtin_bit_cast(bf16x8_t, gv), qB = __builtin_bit_cast(bf16x8_t, xv);
+#pragma unroll
+        for (int tk = 0; tk < 2; ++tk) {
+          dv[tk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(swm_pack8(sa[tk], 8 * s2), gB, dv[tk], 0, 0, 0);
+          dk[tk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(swm_pack8(dp[tk], 8 * s2), qB, dk[tk], 0, 0, 0);
+        }
+      }
+    }
+    SW_LDS_SYNC();   // the dS image is complete
+    // ---- dQ = dS.K (rows q from the dS image, K^T image), then the three stores: lane = column d, registers = rows ----
+#pragma unroll
+    for (int tq = 0; tq < 2; ++tq) {
+      f32x16_t dq;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const bf16x8_t A = *(const bf16x8_t*)(DS + (32 * tq + l31) * SWM_P + (16 * s4 + 8 * hh) * 2);
+        const bf16x8_t B = *(const bf16x8_t*)(KT + l31 * SWM_P + (16 * s4 + 8 * hh) * 2);
+        dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, dq, 0, 0, 0);
+      }
+      char* out_w = (char*)(a.dqkv + (size_t)win * S * a.lddq + h * SW_D);   // uniform base of this (window, head)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int q = 32 * tq + 8 * (r >> 2) + (r & 3) + 4 * hh_o;
+        if (q < S) {
+          bf16_t* dst = (bf16_t*)(out_w + (unsigned)((q * a.lddq + l31_o) * 2));
+          dst[0] = f32_to_bf16(dq[r] * a.scale);
+          dst[a.C] = f32_to_bf16(dk[tq][r] * a.scale);   // (tile index = key tile here: same row numbering)
+          dst[2 * a.C] = f32_to_bf16(dv[tq][r]);
+        }
+      }
+    }
+  }
+  SW_LDS_SYNC();
+  if (a.dbias_part) {
+    float* dst = a.dbias_part + ((size_t)chunk * a.nH + h) * S * S;
+    for (int idx = lane; idx < S * S; idx += 64) dst[idx] = Acc[idx];
+  }
+}
+
 // sum of the per-chunk partials in chunk order: 32 columns x 8 chunk groups per block, groups combined in a fixed order
 __global__ __launch_bounds__(256) void swin_dbias_reduce_kernel(const float* __restrict__ part, int nchunk, size_t n,
                                                                  float* out, int accumulate) {
@@ -368,7 +561,12 @@ extern "C" int lc2is_swin_attn_bwd(const void* qkv, int ld, const void* o, int l
   if (rc) return rc;
   if (ld < 3 * C || lddq < 3 * C || ld_o < C || lddo < C || ld % 8 || lddq % 8 || ld_o % 8 || lddo % 8) return LC2IS_ERR_SHAPE;
   if (dbias && (!workspace || workspace_bytes < lc2is_swin_attn_bwd_workspace_bytes(nwin, ws, nH))) return LC2IS_ERR_WORKSPACE;
-  const int nchunk = sw_chunks(nwin, nH);
+  static const bool use_valu = getenv("LC2IS_SWIN_BWD_VALU") && atoi(getenv("LC2IS_SWIN_BWD_VALU")) != 0;   // A/B switch
+  int nchunk = sw_chunks(nwin, nH);
+  if (!use_valu) {   // the MFMA form holds 34 KB of LDS and ~300 registers: four single-wave blocks per CU, one round of them
+    const int c4 = 1024 / nH > 0 ? 1024 / nH : 1;
+    if (nchunk > c4) nchunk = c4;
+  }
   SwinAttnArgs a{};
   a.qkv = (const bf16_t*)qkv; a.ld = ld; a.o = (const bf16_t*)o; a.ld_o = ld_o; a.dout = (const bf16_t*)dout; a.lddo = lddo;
   a.lse = const_cast<float*>(lse); a.bias = bias; a.dqkv = (bf16_t*)dqkv; a.lddq = lddq;
@@ -377,14 +575,19 @@ extern "C" int lc2is_swin_attn_bwd(const void* qkv, int ld, const void* o, int l
   a.C = C; a.scale = scale; a.chunk = (nwin + nchunk - 1) / nchunk;
   const int S_ = ws * ws;
   const int lds = (2 * S_ * SW_D + S_ * S_ + 2 * S_) * (int)sizeof(float);
+  const int lds_mfma = (3 * 32 + 64) * SWM_P + (64 + 128 + 64) * 4 + (S_ * S_ + 64) * (int)sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)swin_attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)swin_attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)swin_attn_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
       return LC2IS_ERR_LAUNCH;
     attr_set = true;
   }
   const int nchunk_eff = (nwin + a.chunk - 1) / a.chunk;
-  hipLaunchKernelGGL(swin_attn_bwd_kernel, dim3(nchunk_eff * nH), dim3(64), lds, stream, a);
+  if (use_valu)
+    hipLaunchKernelGGL(swin_attn_bwd_kernel, dim3(nchunk_eff * nH), dim3(64), lds, stream, a);
+  else
+    hipLaunchKernelGGL(swin_attn_bwd_mfma_kernel, dim3(nchunk_eff * nH), dim3(64), lds_mfma, stream, a);
   rc = lc2is_check_launch();
   if (rc || !dbias) return rc;
   const size_t n = (size_t)nH * ws * ws * ws * ws;

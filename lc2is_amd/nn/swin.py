@@ -230,7 +230,9 @@ class SwinTransformer(HipModule):
         ws = self.arch.window
         S = ws * ws
         dev = self._sh["wp"].device
-        idx = relative_position_index(ws).to(dev)
+        idx = getattr(self, "_rel_idx", None)
+        if idx is None or idx.device != dev:      # built once: no host-to-device copy per refresh (hipGraph-capturable)
+            idx = self._rel_idx = relative_position_index(ws).to(dev)
         if self._onehot is None or self._onehot.device != dev:
             T = (2 * ws - 1) ** 2
             oh = torch.zeros(T, S * S, dtype=torch.float32, device=dev)
