@@ -81,8 +81,8 @@ int lc2is_gemm_tn_bf16(const void* dY, int ldy, const void* X, int ldx, float* d
  * autograd of an nn.Linear call listed above — or a whole tower's: 12 layers = 72 problems = 1296 output tiles, scheduled as
  * full-length blocks plus a few finely split problems that fill the last round of CUs) in ONE grid and one ordered-reduce
  * launch.  More than 16 problems: the descriptor table is uploaded into the front of the workspace (one small H2D copy on
- * `stream`; such a call cannot be captured into a hipGraph).  Every N and K must be a multiple of 256
- * (LC2IS_ERR_UNSUPPORTED otherwise: call lc2is_gemm_tn_bf16 per problem).  Same results contract: fp32, bitwise
+ * `stream`; such a call cannot be captured into a hipGraph).  N and K multiples of 8; a group whose N and K are all
+ * multiples of 256 runs on the 256x256 LDS-DMA tiles, any other (the Swin blocks) on 128x128 tiles.  Same results contract: fp32, bitwise
  * reproducible, db (optional) = column sums of dY, `accumulate` adds to dW / db. */
 #define LC2IS_TN_GROUP_MAX 128
 typedef struct lc2is_tn_problem {

@@ -85,17 +85,16 @@ __device__ __forceinline__ bf16x8_t tr_frag(const char* tile, int addr_lo, int a
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
-__global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__ dY, int ldy,
+__device__ __forceinline__ void tn_small_body(const bf16_t* __restrict__ dY, int ldy,
                                                        const bf16_t* __restrict__ X, int ldx, float* out,
                                                        int ldo, size_t split_stride, float* bias_out,
                                                        size_t bias_split_stride, int M, int N, int K,
-                                                       int ntn, int ntk, int chunk, int accumulate) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+                                                       int ntn, int ntk, int chunk, int accumulate, int blk_x, char* smem) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wk = wid >> 1, wn = wid & 1;
   const int tiles = ntn * ntk;
-  const int split = blockIdx.x / tiles;
-  const int tile = blockIdx.x % tiles;
+  const int split = blk_x / tiles;
+  const int tile = blk_x % tiles;
   const int n0 = (tile / ntk) * TN_BN, k0 = (tile % ntk) * TN_BK;
   const int m_begin = split * chunk;
   int m_end = m_begin + chunk;
@@ -232,6 +231,16 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
       *(f32x4_t*)dst = v;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__ dY, int ldy,
+                                                       const bf16_t* __restrict__ X, int ldx, float* out,
+                                                       int ldo, size_t split_stride, float* bias_out,
+                                                       size_t bias_split_stride, int M, int N, int K,
+                                                       int ntn, int ntk, int chunk, int accumulate) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  tn_small_body(dY, ldy, X, ldx, out, ldo, split_stride, bias_out, bias_split_stride, M, N, K, ntn, ntk, chunk, accumulate,
+                (int)blockIdx.x, smem);
 }
 
 // ---- 256x256 LDS-DMA variant for the large weight gradients --------------------------------------------------
@@ -416,6 +425,29 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_grouped_tbl_kernel(const TnGro
   const TnGroupProb* q = &t->p[i];
   tn_dma_body(q->dY, q->ldy, q->X, q->ldx, q->out, q->ldo, q->split_stride, q->bias_out, q->bias_split_stride, q->M, q->N,
               q->K, q->ntn, q->ntk, q->chunk, q->splits == 1 ? q->accumulate : 0, (int)blockIdx.x - begin, smem);
+}
+
+// groups whose N / K are not all multiples of 256 (the Swin blocks: 96 .. 768 channels and their 4x MLPs) run the 128x128
+// register-staged body of gemm_tn_kernel per block instead: one grid + one ordered reduce per layer, not two launches per weight
+__global__ __launch_bounds__(256) void gemm_tn_grouped_small_kernel(TnGroup g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int i = 0, begin = 0;
+#pragma unroll 1
+  while (i < g.n - 1 && (int)blockIdx.x >= g.p[i].blk_end) { begin = g.p[i].blk_end; ++i; }
+  const TnGroupProb& q = g.p[i];
+  tn_small_body(q.dY, q.ldy, q.X, q.ldx, q.out, q.ldo, q.split_stride, q.bias_out, q.bias_split_stride, q.M, q.N, q.K, q.ntn,
+                q.ntk, q.chunk, q.splits == 1 ? q.accumulate : 0, (int)blockIdx.x - begin, smem);
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_grouped_small_tbl_kernel(const TnGroupTbl* __restrict__ t) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int i = 0, begin = 0;
+  const int n = t->n;
+#pragma unroll 1
+  while (i < n - 1 && (int)blockIdx.x >= t->blk_end[i]) { begin = t->blk_end[i]; ++i; }
+  const TnGroupProb* q = &t->p[i];
+  tn_small_body(q->dY, q->ldy, q->X, q->ldx, q->out, q->ldo, q->split_stride, q->bias_out, q->bias_split_stride, q->M, q->N,
+                q->K, q->ntn, q->ntk, q->chunk, q->splits == 1 ? q->accumulate : 0, (int)blockIdx.x - begin, smem);
 }
 
 __global__ __launch_bounds__(512, 2) void gemm_tn_grouped_kernel(TnGroup g) {
@@ -619,6 +651,7 @@ struct TgPlan {
   int splits[TG_TBL_MAX];   // M-split count per problem
   int order[TG_TBL_MAX];    // problem indices in grid order (split problems last: their short blocks fill the last round)
   size_t ws_floats;         // slab floats (after the descriptor table when n > TG_MAX)
+  bool small;               // some N or K is not a multiple of 256: 128x128 tiles, register-staged body
 };
 
 inline int tg_valid(const lc2is_tn_problem* pr, int n) {
@@ -626,7 +659,7 @@ inline int tg_valid(const lc2is_tn_problem* pr, int n) {
   for (int i = 0; i < n; ++i) {
     const lc2is_tn_problem& q = pr[i];
     if (!q.dY || !q.X || !q.dW) return LC2IS_ERR_NULL;
-    if (q.M <= 0 || q.N <= 0 || q.K <= 0 || q.N % 256 || q.K % 256) return LC2IS_ERR_UNSUPPORTED;
+    if (q.M <= 0 || q.N <= 0 || q.K <= 0 || q.N % 8 || q.K % 8) return LC2IS_ERR_UNSUPPORTED;
     if (q.ldy < q.N || q.ldx < q.K || q.ldw < q.K || q.ldy % 8 || q.ldx % 8 || q.ldw % 4) return LC2IS_ERR_SHAPE;
     if ((double)(q.M + 64) * q.ldy * 2.0 >= 2147483648.0 || (double)(q.M + 64) * q.ldx * 2.0 >= 2147483648.0)
       return LC2IS_ERR_UNSUPPORTED;
@@ -642,6 +675,28 @@ inline int tg_valid(const lc2is_tn_problem* pr, int n) {
 //            the last, partly empty round (a whole tower, 1296 tiles: 1278 full blocks in 5 rounds + 18 tiles x 14 splits)
 //            — no slabs for the bulk and ~97 % of the CUs busy instead of 84 %.
 inline void tg_plan(const lc2is_tn_problem* pr, int n, TgPlan& pl) {
+  pl.small = false;
+  for (int i = 0; i < n; ++i)
+    if (pr[i].N % 256 || pr[i].K % 256) pl.small = true;
+  if (pl.small) {
+    // 128x128 tiles, two 256-thread blocks per CU (64 KB of LDS each): aim at ~1024 blocks for the group, at least 8 steps
+    // of 64 rows per block (at least 32 once the grid is that full anyway: Swin stage 1 has few tiles over 260k rows)
+    long tiles = 0;
+    for (int i = 0; i < n; ++i) tiles += (long)((pr[i].N + TN_BN - 1) / TN_BN) * ((pr[i].K + TN_BK - 1) / TN_BK);
+    pl.ws_floats = 0;
+    for (int i = 0; i < n; ++i) {
+      int sp = (int)((1024 + tiles / 2) / tiles);
+      int max_sp = (pr[i].M + 511) / 512;
+      const int long_sp = (pr[i].M + 2047) / 2048;
+      if (tiles * long_sp >= 512) max_sp = long_sp;
+      if (sp > max_sp) sp = max_sp;
+      if (sp < 1) sp = 1;
+      pl.splits[i] = sp;
+      pl.order[i] = i;
+      if (sp > 1) pl.ws_floats += (size_t)sp * pr[i].N * ((size_t)pr[i].K + 1);
+    }
+    return;
+  }
   long tiles = 0;
   double wbytes = 0;
   int max_steps = 0, max_splits = 1 << 30;
@@ -728,7 +783,8 @@ extern "C" int lc2is_gemm_tn_grouped(const lc2is_tn_problem* problems, int n, vo
     TnGroupProb& d = t.p[k];
     d.dY = (const bf16_t*)q.dY; d.X = (const bf16_t*)q.X; d.dW = q.dW; d.db = q.db;
     d.ldy = q.ldy; d.ldx = q.ldx; d.ldw = q.ldw; d.M = q.M; d.N = q.N; d.K = q.K; d.accumulate = q.accumulate;
-    d.ntn = q.N / 256; d.ntk = q.K / 256;
+    d.ntn = pl.small ? (q.N + TN_BN - 1) / TN_BN : q.N / 256;
+    d.ntk = pl.small ? (q.K + TN_BK - 1) / TN_BK : q.K / 256;
     int chunk = (q.M + pl.splits[i] - 1) / pl.splits[i];
     chunk = (chunk + TN_BM - 1) / TN_BM * TN_BM;
     d.chunk = chunk;
@@ -760,7 +816,11 @@ extern "C" int lc2is_gemm_tn_grouped(const lc2is_tn_problem* problems, int n, vo
     if (hipFuncSetAttribute((const void*)gemm_tn_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             2 * TD_STAGE) != hipSuccess ||
         hipFuncSetAttribute((const void*)gemm_tn_grouped_tbl_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            2 * TD_STAGE) != hipSuccess)
+                            2 * TD_STAGE) != hipSuccess ||
+        hipFuncSetAttribute((const void*)gemm_tn_grouped_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            2 * TN_STAGE) != hipSuccess ||
+        hipFuncSetAttribute((const void*)gemm_tn_grouped_small_tbl_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            2 * TN_STAGE) != hipSuccess)
       return LC2IS_ERR_LAUNCH;
     attr_set = true;
   }
@@ -768,7 +828,10 @@ extern "C" int lc2is_gemm_tn_grouped(const lc2is_tn_problem* problems, int n, vo
     if (hipMemcpyAsync(workspace, &t, sizeof(TnGroupTbl), hipMemcpyHostToDevice, stream) != hipSuccess)
       return LC2IS_ERR_LAUNCH;
     const TnGroupTbl* dt = (const TnGroupTbl*)workspace;
-    hipLaunchKernelGGL(gemm_tn_grouped_tbl_kernel, dim3(blk), dim3(512), 2 * TD_STAGE, stream, dt);
+    if (pl.small)
+      hipLaunchKernelGGL(gemm_tn_grouped_small_tbl_kernel, dim3(blk), dim3(256), 2 * TN_STAGE, stream, dt);
+    else
+      hipLaunchKernelGGL(gemm_tn_grouped_tbl_kernel, dim3(blk), dim3(512), 2 * TD_STAGE, stream, dt);
     rc = lc2is_check_launch();
     if (rc || red == 0) return rc;
     hipLaunchKernelGGL(slab_reduce_grouped_tbl_kernel, dim3(red), dim3(256), 0, stream, dt);
@@ -777,7 +840,10 @@ extern "C" int lc2is_gemm_tn_grouped(const lc2is_tn_problem* problems, int n, vo
   TnGroup g{};
   g.n = n;
   for (int k = 0; k < n; ++k) g.p[k] = t.p[k];
-  hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(blk), dim3(512), 2 * TD_STAGE, stream, g);
+  if (pl.small)
+    hipLaunchKernelGGL(gemm_tn_grouped_small_kernel, dim3(blk), dim3(256), 2 * TN_STAGE, stream, g);
+  else
+    hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(blk), dim3(512), 2 * TD_STAGE, stream, g);
   rc = lc2is_check_launch();
   if (rc || red == 0) return rc;
   hipLaunchKernelGGL(slab_reduce_grouped_kernel, dim3(red), dim3(256), 0, stream, g);

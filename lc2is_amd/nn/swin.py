@@ -25,7 +25,7 @@ import torch
 from torch import nn
 
 from .. import ops
-from .base import HipModule, grad_buf, linear_bwd_params, require_cuda, vec_grad
+from .base import HipModule, WgradBatch, grad_buf, linear_bwd_params, require_cuda, vec_grad
 
 
 @dataclass(frozen=True)
@@ -322,7 +322,8 @@ class SwinTransformer(HipModule):
     def _qkv_wgrad(dqkv16, win16p, at: _Attn, C):
         """q, k and v share their input: one [3C, Cp] weight-gradient GEMM (+ fused bias gradient), then three slices."""
         ps = (at.q_proj, at.k_proj, at.v_proj)
-        if not all(l.weight.requires_grad and l.bias.requires_grad for l in ps):
+        if win16p.shape[1] == C or not all(l.weight.requires_grad and l.bias.requires_grad for l in ps):
+            # unpadded channels (stages 2-4): three strided problems of the block's grouped launch, written in place
             for j, lin in enumerate(ps):
                 SwinTransformer._wgrad_padded(dqkv16[:, j * C:(j + 1) * C], win16p, lin.weight, lin.bias, C)
             return
@@ -362,6 +363,10 @@ class SwinTransformer(HipModule):
         return x_out, sv
 
     def _block_bwd(self, g32, blk: _Block, s, ctx, sv):
+        with WgradBatch():   # the block's weight gradients (q, k, v, o, fc1, fc2) leave as one grouped grid + one ordered reduce
+            return self._block_bwd_inner(g32, blk, s, ctx, sv)
+
+    def _block_bwd_inner(self, g32, blk: _Block, s, ctx, sv):
         a = self.arch
         B, H, W, C, nH = ctx["B"], ctx["H"], ctx["W"], ctx["C"], ctx["nH"]
         Cp, ws, shift = _r64(C), a.window, sv["shift"]

@@ -201,12 +201,12 @@ _GROUP_MIN_ROWS = int(os.environ.get("LC2IS_GROUP_MIN_ROWS", "4096"))
 
 
 def gemm_tn_groupable(dy: torch.Tensor, x: torch.Tensor) -> bool:
-    return dy.shape[1] % 256 == 0 and x.shape[1] % 256 == 0 and dy.shape[0] >= _GROUP_MIN_ROWS
+    return dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0 and dy.shape[0] >= _GROUP_MIN_ROWS
 
 
 def gemm_tn_grouped(problems):
     """problems: list of (dy [M,N] bf16, x [M,K] bf16, dw [N,K] fp32, db [N] fp32 or None, accumulate) with N, K
-    multiples of 256 (check with gemm_tn_groupable) — the weight gradients of one layer, or of a whole tower, in one grid."""
+    multiples of 8 (check with gemm_tn_groupable; groups whose N, K are all multiples of 256 take the 256x256 LDS-DMA tiles) — the weight gradients of one layer, or of a whole tower, in one grid."""
     if not 1 <= len(problems) <= GROUP_MAX:
         raise RuntimeError(f"lc2is_amd.gemm_tn_grouped: 1..{GROUP_MAX} problems per launch")
     arr = (TnProblem * len(problems))()

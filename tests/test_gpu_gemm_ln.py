@@ -273,7 +273,35 @@ def test_gemm_tn_grouped(dev):
     for a, b in zip(again, probs):
         assert torch.equal(a[2], b[2]) and (a[3] is None or torch.equal(a[3], b[3]))   # bitwise reproducible
     with pytest.raises(RuntimeError):
-        ops.gemm_tn_grouped([(probs[0][0][:, :200], probs[0][1], torch.empty(200, 768, device=dev), None, False)] * 2)
+        ops.gemm_tn_grouped([(probs[0][0][:, :204], probs[0][1], torch.empty(204, 768, device=dev), None, False)] * 2)   # N % 8
+
+
+def test_gemm_tn_grouped_small_tiles(dev):
+    """Groups with N or K not a multiple of 256 (Swin: 96 / 192 / 384 channels, 4x MLP) run on the 128x128 body: same results
+    contract as the per-problem launches, ragged tiles included."""
+    from lc2is_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(29)
+    M = 9000
+    shapes = [(96, 96), (288, 96), (384, 96), (96, 384), (200, 136), (768, 192)]
+    probs, refs = [], []
+    for i, (N, K) in enumerate(shapes):
+        dy = _bf(torch.randn(M, N + 8, generator=g)).to(dev)[:, :N]
+        x = _bf(torch.randn(M, K, generator=g)).to(dev)
+        acc = i % 2 == 0
+        dw = torch.full((N, K), 2.0, device=dev)
+        db = torch.full((N,), 3.0, device=dev) if i != 1 else None
+        probs.append((dy, x, dw, db, acc))
+        refs.append((dy.double().T @ x.double() + (2.0 if acc else 0.0), dy.double().sum(0) + (3.0 if acc else 0.0)))
+    assert all(ops.gemm_tn_groupable(p[0], p[1]) for p in probs)
+    ops.gemm_tn_grouped(probs)
+    for (dy, x, dw, db, acc), (rw, rb) in zip(probs, refs):
+        assert _rel(dw, rw) < 1e-5
+        if db is not None:
+            assert _rel(db, rb) < 1e-5
+    again = [(dy, x, torch.full_like(dw, 2.0), None if db is None else torch.full_like(db, 3.0), acc) for dy, x, dw, db, acc in probs]
+    ops.gemm_tn_grouped(again)
+    for a, b in zip(again, probs):
+        assert torch.equal(a[2], b[2]) and (a[3] is None or torch.equal(a[3], b[3]))
 
 
 def test_gemm_tn_grouped_whole_tower_table_and_tail_split(dev):
