@@ -142,8 +142,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=2)
     ap.add_argument("--cpu-steps", type=int, default=2)
-    ap.add_argument("--graph", action="store_true", help="replay the step as one hipGraph (single GPU, SGD); measured "
-                    "equal to eager launches at B=32 — the step is GPU-bound, not launch-bound")
+    ap.add_argument("--graph", action="store_true", help="replay the step as one hipGraph (single GPU, SGD); one captured stream, so "
+                    "slower than eager (795 vs 862 img/s): the step is GPU-bound and eager overlaps the text tower on a side stream")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI) | gloo (wiring tests on one GPU)")
     args = ap.parse_args()
 
