@@ -4,14 +4,13 @@
 //     pad + cyclic shift + window partition (modeling_swin.py:546-550), window reverse + un-shift + un-pad + the
 //     residual add (:558-567), and the 2x2 patch-merging concat (:318-321).  HBM-bound, 16-byte lanes.
 //   * window attention (modeling_swin.py:373-398, 428-465): one wave per (window, head); S = ws*ws <= 64 tokens,
-//     head_dim 32; lane i owns query row i, keys/values are broadcast from LDS; logits get the per-head relative
-//     position bias [nH, S, S] and, for shifted blocks, the region mask computed from the window's position
-//     (-100 where the 3x3 cyclic-shift regions of query and key differ, :584-607).  fp32 math, bf16 I/O.
-//     Backward: pass A (lane = query) forms P and dS in LDS and dQ; pass B (lane = key) reads their columns for
-//     dK, dV; dS is accumulated per (head, window-chunk) in LDS in window order and written as partials that a second
-//     launch sums in chunk order (bias-table gradient, bitwise reproducible, no atomics).
-//   These tiny-tile attentions are latency/HBM-bound (16 MFMA-tiles of work per wave), so round 1 keeps them on the
-//   VALU; the GEMMs of the blocks run on the shared MFMA kernels.
+//     head_dim 32; logits get the per-head relative position bias [nH, S, S] and, for shifted blocks, the region mask
+//     computed from the window's position (-100 where the 3x3 cyclic-shift regions of query and key differ, :584-607).
+//     bf16 I/O, fp32 softmax.  Forward and backward run on the matrix cores (swin_attn_fwd_mfma_kernel: 16, and
+//     swin_attn_bwd_mfma_kernel: 40 v_mfma_f32_32x32x16_bf16 per window-head, rows padded to 64 with zeros); the bias-table
+//     gradient dS is accumulated per (head, window-chunk) in LDS in window order and written as partials that a second
+//     launch sums in chunk order (bitwise reproducible, no atomics).  The first, VALU forms (lane = query row, K / V
+//     broadcast from LDS) stay behind LC2IS_SWIN_FWD_VALU / LC2IS_SWIN_BWD_VALU: 108 vs ~45 and 636 vs 98 us per launch.
 #include "common.h"
 #include "lc2is_hip.h"
 #include <cstdlib>
@@ -466,6 +465,122 @@ __global__ __launch_bounds__(64) void swin_attn_bwd_mfma_kernel(SwinAttnArgs a) 
   }
 }
 
+// ---- forward on the matrix cores: "query on the lane" (the orientation of attention_fwd.hip) --------------------------------
+// One wave per block, block (h, chunk) walks its windows; the head's [S][S] bias tile is loaded into LDS once per block.
+//   S^T[key][q] = K.Q^T  (A = K row fragments, B = Q row fragments, both straight from global memory): lane = query, the
+//   registers of a tile = 16 keys, so the softmax statistics are per-lane loops plus one lane^32 exchange;
+//   O^T[d][q] += V^T.P^T with the exp'd score registers, packed to bf16, as the B operand and V^T read from an LDS image in
+//   the matching key order (keys key0+{0..3}, key0+8+{0..3}, key0 = 32tk + 16s2 + 4hh).  16 MFMAs per (window, head).
+__global__ __launch_bounds__(64) void swin_attn_fwd_mfma_kernel(SwinAttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x, l31 = lane & 31, hh = lane >> 5;
+  const int S = a.ws * a.ws;
+  const int h = blockIdx.x % a.nH, chunk = blockIdx.x / a.nH;
+  char* VT = smem;                              // [32 d][SWM_P]  V^T (bf16)
+  int* Rid = (int*)(VT + 32 * SWM_P);           // [64]
+  float* Bs = (float*)(Rid + 64);               // [S][S] bias of head h
+  for (int idx = lane; idx < S * S; idx += 64) Bs[idx] = a.bias[(size_t)h * S * S + idx];
+  const int w_begin = chunk * a.chunk;
+  int w_end = w_begin + a.chunk;
+  if (w_end > a.nwin) w_end = a.nwin;
+  const float NEG = -__builtin_inff();
+  const bf16x8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int win = w_begin; win < w_end; ++win) {
+    int opq = 0;   // ties the per-lane offsets to the iteration (see the backward kernel)
+    asm volatile("" : "+v"(opq));
+    const int hh_o = hh + opq, l31_o = l31 + opq;
+    bf16x8_t qf[2][2], kf[2][2], vf[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int r = 32 * t + l31_o;
+      const bool ok = r < S;
+      const size_t row = (size_t)win * S + (ok ? r : 0);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int col = h * SW_D + 16 * s2 + 8 * hh_o;
+        qf[t][s2] = ok ? *(const bf16x8_t*)(a.qkv + row * a.ld + col) : zero8;
+        kf[t][s2] = ok ? *(const bf16x8_t*)(a.qkv + row * a.ld + a.C + col) : zero8;
+        vf[t][s2] = ok ? *(const bf16x8_t*)(a.qkv + row * a.ld + 2 * a.C + col) : zero8;
+      }
+    }
+    const int widx = win % a.win_per_img, wy = widx / a.nwx, wx = widx % a.nwx;
+    int rid_l = -1;
+    if (lane < S && a.shift > 0)
+      rid_l = sw_region(wy * a.ws + lane / a.ws, a.Hp, a.ws, a.shift) * 3 + sw_region(wx * a.ws + lane % a.ws, a.Wp, a.ws, a.shift);
+    SW_LDS_SYNC();   // the previous window is done with the image
+    Rid[lane] = rid_l;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          *(__bf16*)(VT + (16 * s2 + 8 * hh + e) * SWM_P + (32 * t + l31) * 2) = vf[t][s2][e];
+    SW_LDS_SYNC();
+#pragma unroll
+    for (int tq = 0; tq < 2; ++tq) {
+      const int q = 32 * tq + l31_o;
+      const bool q_ok = q < S;
+      const int qc = q_ok ? q : S - 1;
+      const int rid_q = Rid[q];
+      f32x16_t st[2];
+#pragma unroll
+      for (int tk = 0; tk < 2; ++tk) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[tk][r] = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) st[tk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[tk][s2], qf[tq][s2], st[tk], 0, 0, 0);
+      }
+      float m = NEG;
+#pragma unroll
+      for (int tk = 0; tk < 2; ++tk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = 32 * tk + 8 * (r >> 2) + (r & 3) + 4 * hh_o;
+          const int kc = key < S ? key : S - 1;
+          float sc = st[tk][r] * a.scale + Bs[qc * S + kc];
+          sc += (a.shift > 0 && Rid[key] != rid_q) ? -100.0f : 0.f;
+          sc = key < S ? sc : NEG;
+          st[tk][r] = sc;
+          m = fmaxf(m, sc);
+        }
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      float l = 0.f;
+#pragma unroll
+      for (int tk = 0; tk < 2; ++tk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = __expf(st[tk][r] - m);
+          st[tk][r] = p;
+          l += p;
+        }
+      l += __shfl_xor(l, 32, 64);
+      f32x16_t ot;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ot[r] = 0.f;
+#pragma unroll
+      for (int tk = 0; tk < 2; ++tk)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int key0 = 32 * tk + 16 * s2 + 4 * hh;
+          const s16x4_t v0 = *(const s16x4_t*)(VT + l31 * SWM_P + key0 * 2), v1 = *(const s16x4_t*)(VT + l31 * SWM_P + (key0 + 8) * 2);
+          const s16x8_t vv = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          ot = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vv), swm_pack8(st[tk], 8 * s2), ot, 0, 0, 0);
+        }
+      if (q_ok) {
+        const float inv = 1.0f / l;
+        bf16_t* orow = a.out + ((size_t)win * S + q) * a.ldo + h * SW_D;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          i32x2_t pk = {(int)pack_bf16x2(ot[4 * c] * inv, ot[4 * c + 1] * inv), (int)pack_bf16x2(ot[4 * c + 2] * inv, ot[4 * c + 3] * inv)};
+          *(i32x2_t*)(orow + 8 * c + 4 * hh) = pk;
+        }
+        if (a.lse && hh == 0) a.lse[((size_t)win * a.nH + h) * S + q] = m + __logf(l);
+      }
+    }
+  }
+}
+
 // sum of the per-chunk partials in chunk order: 32 columns x 8 chunk groups per block, groups combined in a fixed order
 __global__ __launch_bounds__(256) void swin_dbias_reduce_kernel(const float* __restrict__ part, int nchunk, size_t n,
                                                                  float* out, int accumulate) {
@@ -541,7 +656,19 @@ extern "C" int lc2is_swin_attn_fwd(const void* qkv, int ld, void* out, int ldo, 
       return LC2IS_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL(swin_attn_fwd_kernel, dim3((int)((pairs + 3) / 4)), dim3(256), lds, stream, a);
+  static const bool use_valu = getenv("LC2IS_SWIN_FWD_VALU") && atoi(getenv("LC2IS_SWIN_FWD_VALU")) != 0;   // A/B switch
+  if (use_valu) {
+    hipLaunchKernelGGL(swin_attn_fwd_kernel, dim3((int)((pairs + 3) / 4)), dim3(256), lds, stream, a);
+    return lc2is_check_launch();
+  }
+  // matrix-core form: single-wave blocks, ~14 KB of LDS each (8 resident per CU), one round of them
+  int nchunk = 2048 / nH > 0 ? 2048 / nH : 1;
+  if (nchunk > nwin) nchunk = nwin;
+  a.chunk = (nwin + nchunk - 1) / nchunk;
+  const int nchunk_eff = (nwin + a.chunk - 1) / a.chunk;
+  const int S_ = ws * ws;
+  const int lds_mfma = 32 * SWM_P + 64 * 4 + S_ * S_ * (int)sizeof(float);
+  hipLaunchKernelGGL(swin_attn_fwd_mfma_kernel, dim3(nchunk_eff * nH), dim3(64), lds_mfma, stream, a);
   return lc2is_check_launch();
 }
 
