@@ -12,7 +12,7 @@
 namespace {
 
 #ifndef LN_BWD_OCC
-#define LN_BWD_OCC 4   // waves per SIMD the backward is compiled for (<= 128 VGPRs): measured against 3
+#define LN_BWD_OCC 4   // waves per SIMD the backward is compiled for when a lane holds <= 3 float4 groups (C <= 768: <= 128 VGPRs, measured against 3); wider rows get 3 (C <= 1024) or 2: at 4 they spilled 84 .. 368 VGPRs (ViT-L: 196 us per launch)
 #endif
 constexpr int LN_MAXV = 8;  // float4 per lane -> C <= 2048 (kernels are instantiated for NV = 1,2,3,4,6,8)
 
@@ -87,7 +87,7 @@ __device__ __forceinline__ float4 load_dy4(const bf16_t* dyb, const float* dyf, 
 // grid = nblk blocks of 4 waves; wave w of block b walks rows b*4+w, +4*nblk, ...
 // partial dgamma/dbeta per block -> ws[b][0][C], ws[b][1][C]
 template <int NV>
-__global__ __launch_bounds__(256, LN_BWD_OCC) void ln_bwd_kernel(const bf16_t* __restrict__ dyb, int lddy,
+__global__ __launch_bounds__(256, (NV <= 3 ? LN_BWD_OCC : NV == 4 ? 3 : 2)) void ln_bwd_kernel(const bf16_t* __restrict__ dyb, int lddy,
                                                       const float* __restrict__ dyf, int lddyf,
                                                       const float* __restrict__ x, int ldx,
                                                       const float* __restrict__ gamma,
@@ -186,9 +186,12 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
   if (dbeta) dbeta[c] = accumulate ? dbeta[c] + b : b;
 }
 
-inline int ln_bwd_blocks(int M) {
+// one resident round of 4-wave blocks: 256 CUs x the waves per SIMD the instantiation is compiled for
+inline int ln_bwd_blocks(int M, int C) {
+  const int nv = (C / 4 + 63) / 64;
+  const int cap = 256 * (nv <= 3 ? LN_BWD_OCC : nv == 4 ? 3 : 2);
   int nb = (M + 3) / 4;
-  return nb > 1024 ? 1024 : nb;
+  return nb > cap ? cap : nb;
 }
 
 }  // namespace
@@ -213,7 +216,7 @@ extern "C" int lc2is_layernorm_fwd(const float* x, int ldx, const float* gamma, 
 
 extern "C" size_t lc2is_layernorm_bwd_workspace_bytes(int M, int C) {
   if (M <= 0 || C <= 0) return 0;
-  return (size_t)ln_bwd_blocks(M) * 2 * (size_t)C * sizeof(float);
+  return (size_t)ln_bwd_blocks(M, C) * 2 * (size_t)C * sizeof(float);
 }
 
 extern "C" int lc2is_layernorm_bwd(const void* dy_bf16, int lddy, const float* dy_f32, int lddyf,
@@ -231,7 +234,7 @@ extern "C" int lc2is_layernorm_bwd(const void* dy_bf16, int lddy, const float* d
       (dx_bf16 && (lddxb < C || lddxb % 4)))
     return LC2IS_ERR_SHAPE;
   if (!workspace || workspace_bytes < lc2is_layernorm_bwd_workspace_bytes(M, C)) return LC2IS_ERR_WORKSPACE;
-  const int nblk = ln_bwd_blocks(M);
+  const int nblk = ln_bwd_blocks(M, C);
 #define LN_BWD(NV_)                                                                                   \
   hipLaunchKernelGGL(ln_bwd_kernel<NV_>, dim3(nblk), dim3(256), 0, stream, (const bf16_t*)dy_bf16, lddy, \
                      dy_f32, lddyf, x, ldx, gamma, mean, rstd, dres, lddres, dx_f32, lddx,              \
