@@ -825,6 +825,8 @@ extern "C" int lc2is_gemm_tn_grouped(const lc2is_tn_problem* problems, int n, vo
     attr_set = true;
   }
   if (tbl) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;   // a captured copy would re-read this host ring at every replay
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return LC2IS_ERR_UNSUPPORTED;
     if (hipMemcpyAsync(workspace, &t, sizeof(TnGroupTbl), hipMemcpyHostToDevice, stream) != hipSuccess)
       return LC2IS_ERR_LAUNCH;
     const TnGroupTbl* dt = (const TnGroupTbl*)workspace;
