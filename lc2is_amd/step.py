@@ -16,6 +16,8 @@ the remaining backward (``lc2is_amd.dp.GradReducer``).
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import nn
 
@@ -75,8 +77,8 @@ class TrainStep:
         Single-process only (the RCCL reduction is not captured)."""
         if self.reducer is not None:
             raise RuntimeError("TrainStep.capture: graph capture is only wired for single-GPU steps")
-        if hasattr(self.model, "overlap_text"):
-            self.model.overlap_text = False   # one captured stream: the side-stream fork is an eager-mode optimisation
+        if hasattr(self.model, "overlap_text") and os.environ.get("LC2IS_GRAPH_OVERLAP", "0") != "1":
+            self.model.overlap_text = False   # one captured stream (LC2IS_GRAPH_OVERLAP=1: capture the text-tower fork / join too)
         static_in = {k: v.clone() for k, v in inputs.items()}
         static_lb = labels.clone()
         side = torch.cuda.Stream()
