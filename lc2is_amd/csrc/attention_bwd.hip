@@ -92,15 +92,17 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dq_kernel(Att
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int hh = lane >> 5, l31 = lane & 31;
-  const int head = blockIdx.y, b = blockIdx.z;
-  const int qrow = blockIdx.x * 128 + wid * 32 + l31;
+  const int nqb = (p.Sq + 127) / 128;   // 1-D XCD-aware grid (see attention_fwd.hip)
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int bx = tile % nqb, head = (tile / nqb) % p.H, b = tile / (nqb * p.H);
+  const int qrow = bx * 128 + wid * 32 + l31;
   const bool qok = qrow < p.Sq;
-  const bool wave_active = (int)(blockIdx.x * 128 + wid * 32) < p.Sq;   // wave-uniform
+  const bool wave_active = (int)(bx * 128 + wid * 32) < p.Sq;   // wave-uniform
   const float INF = __builtin_inff();
 
   int nkt = (p.Sk + 63) / 64;
   if (p.causal) {
-    const int lim = (blockIdx.x * 128 + 128 + 63) / 64;
+    const int lim = (bx * 128 + 128 + 63) / 64;
     if (lim < nkt) nkt = lim;
   }
 
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dq_kernel(Att
     const bool more = (kt + 1) < nkt;
     if (more) gload(kt + 1);
     const float* biasv = (const float*)(cur + 2 * I::TILE);
-    const bool diag = p.causal && (kt * 64 + 63 > blockIdx.x * 128);
+    const bool diag = p.causal && (kt * 64 + 63 > bx * 128);
     const bool masked = diag || (kt * 64 + 64 > p.Sk) || (p.kbias != nullptr);
 
     if (wave_active) {   // waves past Sq (ragged last block) only help staging: one wave-uniform branch around the compute
@@ -280,14 +282,16 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(A
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int hh = lane >> 5, l31 = lane & 31;
-  const int head = blockIdx.y, b = blockIdx.z;
-  const int kcol = blockIdx.x * 128 + wid * 32 + l31;
+  const int nkb = (p.Sk + 127) / 128;   // 1-D XCD-aware grid: the key blocks of one (batch, head) sweep the same Q / dO
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int bx = tile % nkb, head = (tile / nkb) % p.H, b = tile / (nkb * p.H);
+  const int kcol = bx * 128 + wid * 32 + l31;
   const bool kok = kcol < p.Sk;
-  const bool wave_active = (int)(blockIdx.x * 128 + wid * 32) < p.Sk;   // wave-uniform
+  const bool wave_active = (int)(bx * 128 + wid * 32) < p.Sk;   // wave-uniform
   const float INF = __builtin_inff();
 
   const int nqt = (p.Sq + 63) / 64;
-  const int qt0 = p.causal ? (blockIdx.x * 128) / 64 : 0;  // earlier queries see none of these keys
+  const int qt0 = p.causal ? (bx * 128) / 64 : 0;  // earlier queries see none of these keys
 
   const __amdgpu_buffer_rsrc_t rsQ = make_rsrc(p.Q, (unsigned)p.B * p.Sq * p.ldq * 2u);
   const __amdgpu_buffer_rsrc_t rsdO = make_rsrc(p.dO, (unsigned)p.B * p.Sq * p.lddo * 2u);
@@ -374,7 +378,7 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(A
     if (more) gload(qt + 1);
     const float* lsev = (const float*)(cur + 2 * I::TILE);
     const float* delv = lsev + 64;
-    const bool diag = p.causal && (blockIdx.x * 128 + 127 > qt * 64);  // some key may exceed some query
+    const bool diag = p.causal && (bx * 128 + 127 > qt * 64);  // some key may exceed some query
 
     if (wave_active) {   // waves past Sk (ragged last block) only help staging
 #pragma unroll
@@ -464,10 +468,10 @@ int launch_attn_bwd(const AttnBwdArgs& a, hipStream_t stream) {
       return LC2IS_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL(k1, dim3((a.Sq + 127) / 128, a.H, a.B), dim3(256), LDS_DQ, stream, a);
+  hipLaunchKernelGGL(k1, dim3(((a.Sq + 127) / 128) * a.H * a.B), dim3(256), LDS_DQ, stream, a);
   int rc = lc2is_check_launch();
   if (rc) return rc;
-  hipLaunchKernelGGL(k2, dim3((a.Sk + 127) / 128, a.H, a.B), dim3(256), LDS_KV, stream, a);
+  hipLaunchKernelGGL(k2, dim3(((a.Sk + 127) / 128) * a.H * a.B), dim3(256), LDS_KV, stream, a);
   return lc2is_check_launch();
 }
 

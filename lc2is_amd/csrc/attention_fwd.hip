@@ -64,15 +64,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnFwdArgs p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int hh = lane >> 5, l31 = lane & 31;
-  const int head = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * 128 + wid * 32;
+  // 1-D grid, XCD-aware: the query blocks of one (batch, head) — which stream the same K / V — are neighbours in the tile
+  // order, and xcd_remap gives every XCD (its own L2) one contiguous chunk of that order
+  const int nqb = (p.Sq + 127) / 128;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int bx = tile % nqb, head = (tile / nqb) % p.H, b = tile / (nqb * p.H);
+  const int q0 = bx * 128 + wid * 32;
   const int qrow = q0 + l31;
   const bool wave_active = q0 < p.Sq;   // wave-uniform (wid comes from threadIdx.x >> 6)
   const float NEG_INF = -__builtin_inff();
 
   int nkt = (p.Sk + 63) / 64;
   if (p.causal) {
-    const int lim = (blockIdx.x * 128 + 128 + 63) / 64;  // keys <= last query of the block
+    const int lim = (bx * 128 + 128 + 63) / 64;  // keys <= last query of the block
     if (lim < nkt) nkt = lim;
   }
 
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnFwdArgs p) {
     // ---- softmax update: interior tiles (no bias, no causal edge, full 64 keys) take a branch-free path with
     // one fma + one exp per score; edge tiles take the general masked path ----
     const bool tail = (kt * 64 + 64 > p.Sk);
-    const bool diag = p.causal && (kt * 64 + 63 > blockIdx.x * 128);  // some key may exceed some query
+    const bool diag = p.causal && (kt * 64 + 63 > bx * 128);  // some key may exceed some query
     const bool masked = tail || diag || (p.kbias != nullptr);
     float alpha, psum = 0.f;
     if (DBG & 1) {
@@ -293,7 +297,7 @@ int launch_attn_fwd(const AttnFwdArgs& a, hipStream_t stream) {
   }
   static const int lds_pad = getenv("LC2IS_ATTN_LDS_PAD") ? atoi(getenv("LC2IS_ATTN_LDS_PAD")) : 0;   // occupancy probe (tools/attn_ablate.py)
   if (lds_pad) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Cfg::STAGE + lds_pad);
-  hipLaunchKernelGGL(kern, dim3((a.Sq + 127) / 128, a.H, a.B), dim3(256), 2 * Cfg::STAGE + lds_pad, stream, a);
+  hipLaunchKernelGGL(kern, dim3(((a.Sq + 127) / 128) * a.H * a.B), dim3(256), 2 * Cfg::STAGE + lds_pad, stream, a);
   return lc2is_check_launch();
 }
 
