@@ -87,7 +87,7 @@ __device__ __forceinline__ float4 load_dy4(const bf16_t* dyb, const float* dyf, 
 // grid = nblk blocks of 4 waves; wave w of block b walks rows b*4+w, +4*nblk, ...
 // partial dgamma/dbeta per block -> ws[b][0][C], ws[b][1][C]
 template <int NV>
-__global__ __launch_bounds__(256, (NV <= 3 ? LN_BWD_OCC : NV == 4 ? 3 : 2)) void ln_bwd_kernel(const bf16_t* __restrict__ dyb, int lddy,
+__global__ __launch_bounds__(256, (NV <= 3 ? LN_BWD_OCC : NV == 4 ? 3 : NV <= 6 ? 2 : 1)) void ln_bwd_kernel(const bf16_t* __restrict__ dyb, int lddy,
                                                       const float* __restrict__ dyf, int lddyf,
                                                       const float* __restrict__ x, int ldx,
                                                       const float* __restrict__ gamma,
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
 // one resident round of 4-wave blocks: 256 CUs x the waves per SIMD the instantiation is compiled for
 inline int ln_bwd_blocks(int M, int C) {
   const int nv = (C / 4 + 63) / 64;
-  const int cap = 256 * (nv <= 3 ? LN_BWD_OCC : nv == 4 ? 3 : 2);
+  const int cap = 256 * (nv <= 3 ? LN_BWD_OCC : nv == 4 ? 3 : nv <= 6 ? 2 : 1);
   int nb = (M + 3) / 4;
   return nb > cap ? cap : nb;
 }
