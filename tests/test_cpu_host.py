@@ -33,6 +33,31 @@ def test_workspace_size_queries_are_pure_host_functions():
     assert ops._fn("lc2is_layernorm_bwd_workspace_bytes")(10, 64) == 3 * 2 * 64 * 4
 
 
+def test_grouped_weight_gradient_planner_on_the_host():
+    """The grouped-launch planner is host code: its slab workspace tells which plan it chose.
+    One ViT-B layer (108 tiles): every problem split in two.  The whole tower (72 problems, 1296 tiles = 5 rounds + 16):
+    full-length blocks for the bulk, only two 9-tile problems split 14-way to fill the last round (+ the descriptor table).
+    A group off the 256 grid (Swin block) takes the 128x128 plan."""
+    from lc2is_amd import ops
+    M, C, F = 32800, 768, 3072
+    layer = [(C, C)] * 4 + [(F, C), (C, F)]           # q, k, v, o, fc1, fc2 as (N, K)
+
+    def ws_bytes(shapes):
+        arr = (ops.TnProblem * len(shapes))()
+        for i, (N, K) in enumerate(shapes):
+            arr[i] = ops.TnProblem(0x1000, 0x1000, 0x1000, 0x1000, N, K, K, M, N, K, 0)   # pointers are not dereferenced
+        return ops._fn("lc2is_gemm_tn_grouped_workspace_bytes")(arr, len(shapes))
+
+    slab = lambda sp, N, K: sp * N * (K + 1) * 4
+    assert ws_bytes(layer) == sum(slab(2, N, K) for N, K in layer)
+    tower = ws_bytes(layer * 12)
+    table = tower - 2 * slab(14, C, C)
+    assert 0 < table <= 32768 and table % 256 == 0
+    swin = [(384, 384)] * 4 + [(1536, 384), (384, 1536)]
+    assert ws_bytes(swin) > 0 and ws_bytes(swin) % 4 == 0
+    assert ws_bytes([(100, 100)]) == 0                # N % 8 != 0: refused
+
+
 def test_launchers_refuse_bad_arguments_without_touching_a_gpu():
     """Argument validation happens before any HIP call: NULL pointers / bad shapes return negative codes."""
     from lc2is_amd import _lib, ops
