@@ -125,7 +125,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_ce_kernel(HeadArgs p) {
   for (int px = 0; px < 32; ++px) {
     const int Y = Y0 + 2 * wid + (px >> 4), X = X0 + (px & 15);
     if (Y >= p.H || X >= p.W) continue;  // wave-uniform
-    const int label = __shfl(my_label, px, 64);
+    const int label = __builtin_amdgcn_readlane(my_label, px);   // wave-uniform lane index: v_readlane, not an LDS bpermute
     const Taps ay = make_taps(Y, inv_scale, p.h, MODE);
     const Taps ax = make_taps(X, inv_scale, p.w, MODE);
     float v[3] = {0.f, 0.f, 0.f};
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_ce_kernel(HeadArgs p) {
     if (!counted) continue;
     const int lsel = label >> 6, llane = label & 63;
     const float vsel = lsel == 0 ? v[0] : (lsel == 1 ? v[1] : v[2]);
-    const float logit_l = __shfl(vsel, llane, 64);
+    const float logit_l = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vsel), llane));
     loss_acc += (m + __logf(ssum)) - logit_l;
     cnt_acc += 1.f;
     if (p.dlo) {
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_ce_s4_kernel(HeadArgs p) {
             if (c_ok[2]) o[(size_t)(lane + 128) * plane] = lg[2];
           }
           if (!p.loss_sum) continue;
-          const int label = __shfl(my_label, 16 * g2 + 4 * py + px, 64);
+          const int label = __builtin_amdgcn_readlane(my_label, 16 * g2 + 4 * py + px);   // wave-uniform index: v_readlane
           float m = fmaxf(fmaxf(c_ok[0] ? lg[0] : NEG, c_ok[1] ? lg[1] : NEG), c_ok[2] ? lg[2] : NEG);
           m = wave_max(m);
           float e[3];
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_ce_s4_kernel(HeadArgs p) {
           if (label < 0) continue;
           const int lsel = label >> 6, llane = label & 63;
           const float vsel = lsel == 0 ? lg[0] : (lsel == 1 ? lg[1] : lg[2]);
-          loss_acc += (m + __logf(ssum)) - __shfl(vsel, llane, 64);
+          loss_acc += (m + __logf(ssum)) - __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vsel), llane));
           cnt_acc += 1.f;
           if (p.dlo) {
             const float inv = p.gscale / ssum;
