@@ -1158,7 +1158,17 @@ int launch_by_cfg(const GemmNtArgs& a_in, int cfg, hipStream_t stream) {
         default: return launch_dma<256, 256, 2, 4>(a, stream);   // codes 5 / 6 (experiments) keep the run-time switch
       }
     case 5: return launch_dma<256, 128, 4, 2>(a, stream);
-    case 6: return f32_staged ? launch_dma<128, 128, 2, 2, 0, -2>(a, stream) : launch_dma<128, 128, 2, 2>(a, stream);
+    case 6:
+      if (f32_staged) return launch_dma<128, 128, 2, 2, 0, -2>(a, stream);
+      if (!per_act) return launch_dma<128, 128, 2, 2>(a, stream);
+      switch (a.act) {   // the activations of the Swin / hierarchical-decoder GEMMs that land on this tile size
+        case LC2IS_ACT_RELU: return launch_dma<128, 128, 2, 2, 0, LC2IS_ACT_RELU>(a, stream);
+        case LC2IS_ACT_DRELU: return launch_dma<128, 128, 2, 2, 0, LC2IS_ACT_DRELU>(a, stream);
+        case LC2IS_ACT_GELU_ERF: return launch_dma<128, 128, 2, 2, 0, LC2IS_ACT_GELU_ERF>(a, stream);
+        case LC2IS_ACT_DGELU_ERF: return launch_dma<128, 128, 2, 2, 0, LC2IS_ACT_DGELU_ERF>(a, stream);
+        case LC2IS_ACT_NONE: return launch_dma<128, 128, 2, 2, 0, LC2IS_ACT_NONE>(a, stream);
+        default: return launch_dma<128, 128, 2, 2>(a, stream);
+      }
     case 7: return launch_pp(a, stream);
     case 8: return launch_ring(a, stream);
     case 9: return launch_duo(a, stream);
