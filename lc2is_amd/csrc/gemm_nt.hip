@@ -1218,9 +1218,10 @@ extern "C" int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw
   int cfg = tile_cfg;
   if (cfg != 0) return launch_by_cfg(a, cfg, stream);
   const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+  static const long cfg6_min = getenv("LC2IS_GEMM_CFG6_MIN") ? atol(getenv("LC2IS_GEMM_CFG6_MIN")) : 128;   // (512 and the register-staged 128x128 kernel below it measured 0.8 % slower on config 5)
   if (!(tiles128 >= 1024 && N % 256 == 0)) {
     if (tiles128 >= 1024 && N % 256 == 0) cfg = 4;
-    else if (tiles128 >= 512) cfg = 6;                   // 128x128 LDS-DMA tiles, 2 blocks/CU
+    else if (tiles128 >= cfg6_min) cfg = 6;              // 128x128 LDS-DMA tiles, 2 blocks/CU
     else if (tiles128 >= 128) cfg = 1;
     else cfg = 3;                                        // small problem: 64x64 tiles to fill the chip
     return launch_by_cfg(a, cfg, stream);
