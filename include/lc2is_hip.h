@@ -67,6 +67,14 @@ int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw, const flo
                        float* out_f32, int ldf, void* aux_out, int ldy, int M, int N, int K, int act,
                        int tile_cfg, lc2is_stream_t stream);
 
+/* Strided-batched plain product, ONE launch: for b < batch, out[b][M,N] = A[b][M,K] · W[b][N,K]^T (no bias / activation);
+ * stride_* are ELEMENT strides between consecutive problems (stride_a, stride_w multiples of 8, outputs multiples of 4).
+ * replaces: torch.einsum('bchw,bkc->bkhw', visual, text) with per-image class embeddings (reference
+ *   model/final.py:355, model/model.py:161,210, model/ftn.py:60) and, on transposed operands, its backward. */
+int lc2is_gemm_nt_bf16_batched(const void* A, int lda, long stride_a, const void* W, int ldw, long stride_w,
+                               void* out_bf16, int ldo, long stride_ob, float* out_f32, int ldf, long stride_of,
+                               int M, int N, int K, int batch, lc2is_stream_t stream);
+
 /* dW[N,K] (fp32) = dY[M,N]^T · X[M,K]  (weight gradient of out = X·W^T), reduced over M.
  * The M range is cut into `splits` slabs (workspace = splits*N*K fp32) summed by a second launch, so
  * the result is bitwise reproducible.  accumulate != 0 adds into dW instead of overwriting.
@@ -149,6 +157,9 @@ int lc2is_cast_f32_bf16(const float* src, int ld_src, void* dst_bf16, int ld_dst
                         lc2is_stream_t stream);
 int lc2is_transpose_bf16(const void* src, int ld_src, void* dst, int ld_dst, int R, int C,
                          lc2is_stream_t stream);
+/* batch of `batch` such transposes in one launch; stride_* = elements between consecutive matrices. */
+int lc2is_transpose_bf16_batched(const void* src, int ld_src, long stride_src, void* dst, int ld_dst, long stride_dst,
+                                 int R, int C, int batch, lc2is_stream_t stream);
 
 /* ViT patch embedding operand: out[(b*G*G + gy*G + gx)][c*p*p + i*p + j] = pixels[b][c][gy*p+i][gx*p+j]
  * (bf16, G = H / patch, trailing pixels dropped like a stride-p conv); columns [3*p*p, ld_out) are zeroed.

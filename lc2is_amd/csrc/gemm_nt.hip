@@ -34,6 +34,8 @@ struct GemmNtArgs {
   int M, N, K, act;
   int staged_epi;  // 1: bf16 epilogue traffic through LDS (needs N % 8 == 0 and 8-element-aligned leading dims);
                    // 2 (host side only, cleared before the launch): fp32-only output through LDS (F32EPI instantiations)
+  // strided-batched form (gemm_nt_kernel only; blockIdx.y = batch): element strides between consecutive problems
+  long bsA, bsW, bsOb, bsOf;
 };
 
 __device__ __forceinline__ float sigmoidf_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }  // v_exp + v_rcp
@@ -380,6 +382,13 @@ __device__ __forceinline__ void gemm_epilogue_f32_lds(const GemmNtArgs& p, f32x4
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmNtArgs p) {
+  if (gridDim.y > 1) {   // strided-batched launch: one independent problem per blockIdx.y
+    const long b = blockIdx.y;
+    p.A += b * p.bsA;
+    p.W += b * p.bsW;
+    if (p.out_bf16) p.out_bf16 += b * p.bsOb;
+    if (p.out_f32) p.out_f32 += b * p.bsOf;
+  }
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int BK = 64;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -1031,7 +1040,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_duo_kernel(GemmNtArgs p) {
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
-int launch_cfg(const GemmNtArgs& a, hipStream_t stream) {
+int launch_cfg(const GemmNtArgs& a, hipStream_t stream, int batch = 1) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int LDS = 2 * (BM + BN) * 128;
   auto kern = gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N>;
@@ -1042,7 +1051,7 @@ int launch_cfg(const GemmNtArgs& a, hipStream_t stream) {
     attr_set = true;
   }
   const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
-  hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(NT), LDS, stream, a);
+  hipLaunchKernelGGL(kern, dim3(ntm * ntn, batch), dim3(NT), LDS, stream, a);
   return lc2is_check_launch();
 }
 
@@ -1257,4 +1266,28 @@ extern "C" int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw
   if (a.out_f32) tail.out_f32 = a.out_f32 + m0 * ldf;
   if (a.aux_out) tail.aux_out = a.aux_out + m0 * ldy;
   return launch_by_cfg(tail, 3, stream);
+}
+
+// Strided-batched plain product: out[b] = A[b] (M x K) . W[b]^T (N x K), b = 0..batch-1, in ONE launch (blockIdx.y = b).
+// replaces: torch.einsum('bchw,bkc->bkhw', visual, text) — one class-embedding matrix PER IMAGE (reference
+// model/final.py:355, model/model.py:161,210, model/ftn.py:60) — and its two backward contractions.
+extern "C" int lc2is_gemm_nt_bf16_batched(const void* A, int lda, long stride_a, const void* W, int ldw, long stride_w,
+                                          void* out_bf16, int ldo, long stride_ob, float* out_f32, int ldf,
+                                          long stride_of, int M, int N, int K, int batch, lc2is_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!A || !W) return LC2IS_ERR_NULL;
+  if (!out_bf16 && !out_f32) return LC2IS_ERR_NULL;
+  if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || batch > 65535) return LC2IS_ERR_SHAPE;
+  if (K % 64 != 0 || N % 4 != 0) return LC2IS_ERR_SHAPE;
+  if (lda < K || ldw < K || lda % 8 || ldw % 8 || stride_a % 8 || stride_w % 8) return LC2IS_ERR_SHAPE;
+  if ((out_bf16 && (ldo < N || ldo % 4 || stride_ob % 4)) || (out_f32 && (ldf < N || ldf % 4 || stride_of % 4)))
+    return LC2IS_ERR_SHAPE;
+  if ((double)(M + 256) * lda * 2.0 >= 2147483648.0 || (double)(N + 256) * ldw * 2.0 >= 2147483648.0)
+    return LC2IS_ERR_UNSUPPORTED;
+  GemmNtArgs a{(const bf16_t*)A, lda, (const bf16_t*)W, ldw, nullptr, nullptr, 0, nullptr, 0,
+               (bf16_t*)out_bf16, ldo, out_f32, ldf, nullptr, 0, M, N, K, LC2IS_ACT_NONE, 0,
+               stride_a, stride_w, stride_ob, stride_of};
+  const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128) * batch;
+  if (tiles128 >= 128) return launch_cfg<128, 128, 2, 2>(a, stream, batch);
+  return launch_cfg<64, 64, 2, 2>(a, stream, batch);
 }

@@ -771,9 +771,24 @@ extern "C" int lc2is_gemm_tn_grouped(const lc2is_tn_problem* problems, int n, vo
   const bool tbl = n > TG_MAX;
   const size_t need = pl.ws_floats * sizeof(float) + (tbl ? TG_TBL_BYTES : 0);
   if (need && (!workspace || workspace_bytes < need)) return LC2IS_ERR_WORKSPACE;
-  static thread_local TnGroupTbl ring[4];   // host image of the table (hipMemcpyAsync stages pageable memory before it
-  static thread_local unsigned ring_pos = 0;  // returns; the ring is slack on top of that)
-  TnGroupTbl& t = ring[ring_pos++ & 3];
+  // Host image of the table: a ring of PINNED slots, each guarded by an event recorded behind its upload, so a slot is
+  // never rewritten while an asynchronous H2D copy may still be reading it (whatever the runtime does with pageable memory).
+  struct TblSlot { TnGroupTbl* host; hipEvent_t done; bool in_flight; };
+  static thread_local TblSlot ring[4] = {};
+  static thread_local unsigned ring_pos = 0;
+  static thread_local TnGroupTbl small_tbl;     // <= TG_MAX problems travel as kernel arguments: plain host memory
+  TblSlot* slot = nullptr;
+  if (tbl) {
+    slot = &ring[ring_pos++ & 3];
+    if (!slot->host) {
+      if (hipHostMalloc((void**)&slot->host, sizeof(TnGroupTbl), hipHostMallocDefault) != hipSuccess ||
+          hipEventCreateWithFlags(&slot->done, hipEventDisableTiming) != hipSuccess)
+        return LC2IS_ERR_LAUNCH;
+    }
+    if (slot->in_flight && hipEventSynchronize(slot->done) != hipSuccess) return LC2IS_ERR_LAUNCH;
+    slot->in_flight = false;
+  }
+  TnGroupTbl& t = tbl ? *slot->host : small_tbl;
   t.n = n;
   float* ws = (float*)((char*)workspace + (tbl ? TG_TBL_BYTES : 0));
   int blk = 0, red = 0;
@@ -827,8 +842,10 @@ extern "C" int lc2is_gemm_tn_grouped(const lc2is_tn_problem* problems, int n, vo
   if (tbl) {
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;   // a captured copy would re-read this host ring at every replay
     if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return LC2IS_ERR_UNSUPPORTED;
-    if (hipMemcpyAsync(workspace, &t, sizeof(TnGroupTbl), hipMemcpyHostToDevice, stream) != hipSuccess)
+    if (hipMemcpyAsync(workspace, &t, sizeof(TnGroupTbl), hipMemcpyHostToDevice, stream) != hipSuccess ||
+        hipEventRecord(slot->done, stream) != hipSuccess)
       return LC2IS_ERR_LAUNCH;
+    slot->in_flight = true;
     const TnGroupTbl* dt = (const TnGroupTbl*)workspace;
     if (pl.small)
       hipLaunchKernelGGL(gemm_tn_grouped_small_tbl_kernel, dim3(blk), dim3(256), 2 * TN_STAGE, stream, dt);

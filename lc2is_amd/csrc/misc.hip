@@ -76,8 +76,11 @@ __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restr
 }
 
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ src, int lds_,
-                                                              bf16_t* dst, int ldd, int R, int C) {
+                                                              bf16_t* dst, int ldd, int R, int C, long bs_src,
+                                                              long bs_dst) {
   __shared__ bf16_t tile[64][66];
+  src += (size_t)blockIdx.z * bs_src;   // batched form: one matrix per blockIdx.z
+  dst += (size_t)blockIdx.z * bs_dst;
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int r = ty; r < 64; r += 4) {
@@ -305,7 +308,17 @@ extern "C" int lc2is_transpose_bf16(const void* src, int ld_src, void* dst, int 
   if (!src || !dst) return LC2IS_ERR_NULL;
   if (R <= 0 || C <= 0 || ld_src < C || ld_dst < R) return LC2IS_ERR_SHAPE;
   hipLaunchKernelGGL(transpose_bf16_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, stream,
-                     (const bf16_t*)src, ld_src, (bf16_t*)dst, ld_dst, R, C);
+                     (const bf16_t*)src, ld_src, (bf16_t*)dst, ld_dst, R, C, 0L, 0L);
+  return lc2is_check_launch();
+}
+
+extern "C" int lc2is_transpose_bf16_batched(const void* src, int ld_src, long stride_src, void* dst, int ld_dst,
+                                            long stride_dst, int R, int C, int batch, lc2is_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!src || !dst) return LC2IS_ERR_NULL;
+  if (R <= 0 || C <= 0 || ld_src < C || ld_dst < R || batch <= 0 || batch > 65535) return LC2IS_ERR_SHAPE;
+  hipLaunchKernelGGL(transpose_bf16_kernel, dim3((C + 63) / 64, (R + 63) / 64, batch), dim3(256), 0, stream,
+                     (const bf16_t*)src, ld_src, (bf16_t*)dst, ld_dst, R, C, stride_src, stride_dst);
   return lc2is_check_launch();
 }
 

@@ -153,25 +153,23 @@ class BaseModelWithText(HipModule):
             _, _, hi = ops.head_upsample_ce(scores, None, B, g, g, K, 4, ops.INTERP_BICUBIC, want_scores=True,
                                             want_loss=False)
             return hi, (dict(dec16=dec16, ft16=ft16, fv16=fv16, dims=(B, P, C, g, K), fused=None) if save else None)
-        if ignore_index >= 0:
-            count = (labels != ignore_index).sum().clamp_min(1).float()
-        else:
-            count = None
-        n = float(B * 16 * g * g)
+        # the kernel writes the gradient of the SUM of the per-pixel losses and counts the pixels it kept (labels that are
+        # negative, == ignore_index or >= K are skipped, head.hip); the 1/count of nn.CrossEntropyLoss's mean is folded
+        # into the upstream-gradient multiply of _head_bwd, from the device-side count (no host sync, no label pass)
         loss2, dlo, _ = ops.head_upsample_ce(scores, labels.contiguous(), B, g, g, K, 4, ops.INTERP_BICUBIC,
-                                             want_grad=save, ignore_index=ignore_index, grad_scale=1.0 / n)
+                                             want_grad=save, ignore_index=ignore_index, grad_scale=1.0)
         loss = loss2[0] / loss2[1]
-        if save and count is not None:
-            dlo.mul_(n / count)
-        return loss, (dict(dec16=dec16, ft16=ft16, fv16=fv16, dims=(B, P, C, g, K), fused=dlo) if save else None)
+        inv_count = (1.0 / loss2[1].clamp_min(1.0)) if save else None
+        return loss, (dict(dec16=dec16, ft16=ft16, fv16=fv16, dims=(B, P, C, g, K), fused=dlo, inv_count=inv_count)
+                      if save else None)
 
     def _head_bwd(self, gout, saved):
         B, P, C, g, K = saved["dims"]
         pp = self.pixel_patch
         psh, sh = pp._sh, self._sh
         if saved["fused"] is not None:
-            ds = saved["fused"]
-            ds16 = ops.cast_bf16(ds if gout is None else ds * gout)  # gout: scalar upstream gradient of the loss
+            ds = saved["fused"]   # d(sum of pixel losses)/d(scores); gout: scalar upstream gradient of the mean loss
+            ds16 = ops.cast_bf16(ds * (saved["inv_count"] if gout is None else gout * saved["inv_count"]))
         else:
             ds = ops.upsample_bwd_nchw(gout.float().contiguous(), B, g, g, K, 4, ops.INTERP_BICUBIC, KPAD)
             ds16 = ops.cast_bf16(ds)

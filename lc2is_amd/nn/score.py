@@ -6,7 +6,7 @@ Reference (model/final.py:350-356; the same four lines at model/model.py:204-212
     score_map = einsum('bchw,bkc->bkhw', visual, text);  score_map = F.interpolate(score_map, "bilinear", x4)
 followed by nn.CrossEntropyLoss()(score_map, labels) in the engine (engine.py:94).
 
-HIP path: L2-normalise both sides (one wave per row), one MFMA GEMM per image for the K class scores at the low
+HIP path: L2-normalise both sides (one wave per row), one strided-batched MFMA GEMM launch for the per-image K class scores at the low
 resolution, then the fused bilinear-x4 + softmax-CE kernel: the [B,K,4h,4w] fp32 map (157 MB/img at 512x512,
 K=150 — "the" bandwidth-bound tensor of config 5) is only materialised when the caller asks for it.
 """
@@ -32,9 +32,9 @@ def _scores_lo(visual, text):
     _, tn16, tinv = ops.l2norm_fwd(t32, want_f32=False)
     tpad = torch.zeros(B, KPAD, C, dtype=torch.bfloat16, device=visual.device)
     tpad[:, :K] = tn16.view(B, K, C)
-    scores = torch.empty(B * P, KPAD, dtype=torch.float32, device=visual.device)
-    for b in range(B):   # per-image class embeddings: one small NT GEMM each
-        ops.gemm_nt(vn16[b * P:(b + 1) * P], tpad[b], None, out_bf16=None, out_f32=scores[b * P:(b + 1) * P])
+    # per-image class embeddings: ONE strided-batched NT launch (blockIdx.y = image)
+    _, scores = ops.gemm_nt_batched(vn16.view(B, P, C), tpad)
+    scores = scores.view(B * P, KPAD)
     return scores, dict(v32=v32, t32=t32, vn16=vn16, tpad=tpad, vinv=vinv, tinv=tinv, dims=(B, P, C, K))
 
 
@@ -42,12 +42,15 @@ def _scores_bwd(ds32, sv):
     """ds32: gradient wrt the low-resolution scores [B*P, KPAD] (fp32)."""
     B, P, C, K = sv["dims"]
     ds16 = ops.cast_bf16(ds32)
-    dvn = torch.empty(B * P, C, dtype=torch.float32, device=ds32.device)
     dtn = torch.empty(B, KPAD, C, dtype=torch.float32, device=ds32.device)
-    for b in range(B):
-        tT = ops.transpose_bf16(sv["tpad"][b])                                     # [C, KPAD]
-        ops.gemm_nt(ds16[b * P:(b + 1) * P], tT, None, out_bf16=None, out_f32=dvn[b * P:(b + 1) * P])
-        ops.gemm_tn(ds16[b * P:(b + 1) * P], sv["vn16"][b * P:(b + 1) * P], dtn[b])
+    tT = ops.transpose_bf16_batched(sv["tpad"])                                    # [B, C, KPAD]
+    _, dvn = ops.gemm_nt_batched(ds16.view(B, P, KPAD), tT)                         # d(normalised visual) [B, P, C]
+    dvn = dvn.view(B * P, C)
+    vn16 = sv["vn16"]
+    probs = [(ds16[b * P:(b + 1) * P], vn16[b * P:(b + 1) * P], dtn[b], None, False) for b in range(B)]
+    gmax = ops.GROUP_MAX_CAPTURABLE if torch.cuda.is_current_stream_capturing() else ops.GROUP_MAX
+    for i in range(0, B, gmax):                                                    # the B weight-gradient-shaped products: one grid
+        ops.gemm_tn_grouped(probs[i:i + gmax])
     dv = ops.l2norm_bwd(dvn, sv["v32"], sv["vinv"])
     dt = ops.l2norm_bwd(dtn[:, :K].reshape(B * K, C).contiguous(), sv["t32"], sv["tinv"])
     return dv.view(B, P, C), dt.view(B, K, C)
@@ -68,7 +71,7 @@ class _ScoreFn(torch.autograd.Function):
         n = float(B * h * scale * h * scale)
         loss2, dlo, _ = ops.head_upsample_ce(scores, labels.contiguous(), B, h, h, K, scale, ops.INTERP_BILINEAR,
                                              want_grad=save, ignore_index=ignore_index, grad_scale=1.0 / n)
-        if save and ignore_index >= 0:
+        if save:   # mean over the pixels the kernel counted (negative / ignore_index / out-of-range labels are skipped)
             dlo.mul_(n / loss2[1].clamp_min(1.0))
         ctx.sv, ctx.fused, ctx.meta = (sv if save else None), dlo, (B, h, K, scale)
         return loss2[0] / loss2[1]

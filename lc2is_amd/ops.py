@@ -17,9 +17,11 @@ from . import _lib
 ACT_NONE, ACT_QUICK_GELU, ACT_RELU, ACT_DQUICK_GELU, ACT_DRELU, ACT_QUICK_GELU_GRAD, ACT_MUL_AUX = 0, 1, 2, 3, 4, 5, 6
 ACT_GELU_ERF, ACT_DGELU_ERF = 7, 8
 
-_P, _I, _F, _Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+_P, _I, _F, _Z, _L = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_long
 _ARGTYPES = {
     "lc2is_gemm_nt_bf16": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
+    "lc2is_gemm_nt_bf16_batched": [_P, _I, _L, _P, _I, _L, _P, _I, _L, _P, _I, _L, _I, _I, _I, _I, _P],
+    "lc2is_transpose_bf16_batched": [_P, _I, _L, _P, _I, _L, _I, _I, _I, _P],
     "lc2is_gemm_tn_workspace_bytes": [_I, _I, _I],
     "lc2is_gemm_tn_bf16": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _Z, _P],
     "lc2is_colsum_workspace_bytes": [_I, _I],
@@ -162,6 +164,35 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None, 
                                    _ld(ao), M, N, K, act, tile_cfg, _stream())
     _lib.check(rc, f"gemm_nt M={M} N={N} K={K}")
     return ob, of, ao
+
+
+def gemm_nt_batched(a: torch.Tensor, w: torch.Tensor, *, out_bf16: torch.Tensor | bool | None = None,
+                    out_f32: torch.Tensor | bool | None = True):
+    """out[b] = a[b] @ w[b].T for every b in ONE launch.  a [B,M,K] bf16, w [B,N,K] bf16 (unit inner stride; any row /
+    batch strides that are multiples of 8 elements).  Returns (out_bf16 [B,M,N] or None, out_f32 [B,M,N] or None)."""
+    _chk(a, torch.bfloat16, "a", 3); _chk(w, torch.bfloat16, "w", 3)
+    Bn, M, K = a.shape
+    if w.shape[0] != Bn or w.shape[2] != K:
+        raise RuntimeError(f"lc2is_amd.gemm_nt_batched: shape mismatch {tuple(a.shape)} vs {tuple(w.shape)}")
+    N = w.shape[1]
+    ob = _out(out_bf16, (Bn, M, N), torch.bfloat16, a.device)
+    of = _out(out_f32, (Bn, M, N), torch.float32, a.device)
+    _chk(ob, torch.bfloat16, "out_bf16", 3); _chk(of, torch.float32, "out_f32", 3)
+    st = lambda t: (0, 0) if t is None else (t.stride(1), t.stride(0))  # noqa: E731
+    rc = _fn("lc2is_gemm_nt_bf16_batched")(_ptr(a), a.stride(1), a.stride(0), _ptr(w), w.stride(1), w.stride(0),
+                                           _ptr(ob), *st(ob), _ptr(of), *st(of), M, N, K, Bn, _stream())
+    _lib.check(rc, f"gemm_nt_batched B={Bn} M={M} N={N} K={K}")
+    return ob, of
+
+
+def transpose_bf16_batched(x: torch.Tensor) -> torch.Tensor:
+    """x [B,R,C] bf16 -> [B,C,R] contiguous, one launch."""
+    _chk(x, torch.bfloat16, "x", 3)
+    Bn, R, Cc = x.shape
+    out = torch.empty((Bn, Cc, R), dtype=torch.bfloat16, device=x.device)
+    rc = _fn("lc2is_transpose_bf16_batched")(_ptr(x), x.stride(1), x.stride(0), _ptr(out), R, Cc * R, R, Cc, Bn, _stream())
+    _lib.check(rc, f"transpose_bf16_batched B={Bn} R={R} C={Cc}")
+    return out
 
 
 def gemm_tn(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor | None = None, accumulate: bool = False,

@@ -389,6 +389,25 @@ def compute_miou(outputs: Tensor, labels: Tensor, n_class: int = 151, ignore_ind
     return float(sum(vals) / len(vals))
 
 
+def evaluate(sd: dict, batches: list, cfg: BaseCfg) -> dict:
+    """Engine.evaluate / eval_loop (engine.py:125-168) for BaseModelWithText: per batch forward under no_grad and
+    ``nn.CrossEntropyLoss()`` (mean over batches of the per-batch losses, :158-165), then ``compute_metrics`` on the
+    concatenated outputs (:128-130) = metrics.compute_mIOU (metrics.py:82-102).  ``batches``: list of
+    (inputs dict incl. "label", metas)."""
+    losses, outs, labs = [], [], []
+    with torch.no_grad():
+        for inputs, _ in batches:
+            inputs = dict(inputs)
+            labels = inputs.pop("label")
+            _, _, logits = base_model_with_text(sd, inputs, cfg)
+            losses.append(float(cross_entropy(logits, labels)))
+            outs.append(logits)
+            labs.append(labels)
+    outputs, labels = torch.cat(outs), torch.cat(labs)
+    return dict(eval_loss=sum(losses) / len(losses), eval_mIOU_label=compute_miou(outputs, labels),
+                outputs=outputs, labels=labels)
+
+
 # ----------------------------------------------------------------------------------------------------------
 # multi-scale decoders (BASELINE config 5): model/hierarchical.py, model/decoder.py:36-134
 # ----------------------------------------------------------------------------------------------------------

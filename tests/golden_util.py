@@ -26,3 +26,36 @@ def ftn_inputs(seed: int, B: int = 1):
     xs = [torch.randn(B, h * h, c, generator=g) for h, c in zip((128, 64, 32, 16), (128, 256, 512, 1024))]
     dout = torch.randn(B, 16384, 512, generator=g) * 0.1
     return xs, dout
+
+
+def prompt_inputs(seed: int, B: int = 2, K: int = 150, P: int = 256, d_model: int = 512, d_kv: int = 1024):
+    """Inputs of the reference's PromptDecoder at its real use (model/model.py:183,200): tgt = K text embeddings,
+    memory = the last Swin stage's P visual tokens of width d_kv; plus an output gradient."""
+    g = torch.Generator().manual_seed(seed)
+    tgt = torch.randn(B, K, d_model, generator=g)
+    mem = torch.randn(B, P, d_kv, generator=g)
+    dout = torch.randn(B, K, d_model, generator=g) * 0.1
+    return tgt, mem, dout
+
+
+def clip_full_inputs(seed: int, B: int = 2, size: int = 64, tokens: int = 17, C: int = 128):
+    g = torch.Generator().manual_seed(seed)
+    pix = torch.randn(B, 3, size, size, generator=g)
+    dout = torch.randn(B, tokens, C, generator=g) * 0.1     # includes the CLS row (token 0)
+    return pix, dout
+
+
+def config1_batch(i: int, in_size: int = 128, out_size: int = 32, L: int = 16):
+    """SURVEY.md §8d config 1 (the 16-image plumbing shard; ADE20K itself is not available offline): image i has
+    pixel_values ~ N(0,1) from seed 1000+i, labels uniform over 151 classes and constant on 4x4 blocks, and the prompt
+    BOS + 10 random tokens + EOS + 4 pads (mask 0).  Returns ``(inputs incl. "label", metas)`` like ADE20KCollator."""
+    g = torch.Generator().manual_seed(1000 + i)
+    pix = torch.randn(1, 3, in_size, in_size, generator=g)
+    lab = torch.randint(0, 151, (1, out_size // 4, out_size // 4), generator=g)
+    lab = lab.repeat_interleave(4, 1).repeat_interleave(4, 2)
+    ids = torch.full((1, L), 49407, dtype=torch.int64)
+    ids[0, 0] = 49406
+    ids[0, 1:11] = torch.randint(1, 49405, (10,), generator=g)
+    mask = torch.zeros(1, L, dtype=torch.int64)
+    mask[0, :12] = 1
+    return dict(pixel_values=pix, input_ids=ids, attention_mask=mask, label=lab), None

@@ -126,3 +126,47 @@ def test_prompt_aliases_exist():
     import lc2is_amd.nn as N
     layer = N.PromptLayer(d_model=128, d_kv=256, nhead=2, batch_first=True)
     assert layer.dropout_p == 0.1 and isinstance(N.PromptDecoder(layer, 2), N.DecoderBlock)
+
+
+def test_evaluator_host_logic_matches_engine_eval_loop():
+    """lc2is_amd.evalloop.Evaluator mirrors Engine.eval_loop (engine.py:134-168): label popped from the batch dict, loss =
+    mean over batches of the per-batch criterion, aux loss x 0.4 when the model returns low_score_map, metric keys
+    prefixed eval_.  (Host logic only: a toy CPU module and torch's CE stand in for the HIP model.)"""
+    import torch
+    from torch import nn
+    from lc2is_amd.evalloop import Evaluator
+
+    class Toy(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = nn.Parameter(torch.randn(5, 3))
+
+        def forward(self, inputs):
+            assert "label" not in inputs and not self.training
+            x = inputs["pixel_values"]                                  # [B,3,h,w]
+            out = torch.einsum("kc,bchw->bkhw", self.w, x)
+            return dict(outputs=out, low_score_map=out[:, :, ::2, ::2])
+
+    class Aux(nn.Module):
+        def forward(self, low, labels):
+            return nn.functional.cross_entropy(low, labels[:, ::2, ::2])
+
+    g = torch.Generator().manual_seed(0)
+    batches = [(dict(pixel_values=torch.randn(b, 3, 4, 4, generator=g), label=torch.randint(0, 5, (b, 4, 4), generator=g)), None)
+               for b in (1, 3, 2)]
+    toy = Toy().train()
+    seen = {}
+
+    def metric(outputs, labels):
+        seen["shapes"] = (tuple(outputs.shape), tuple(labels.shape))
+        return dict(mIOU_label=0.25)
+
+    ev = Evaluator(toy, batches, nn.CrossEntropyLoss(), aux_criterion=Aux(), compute_metrics=metric, device="cpu")
+    got = ev.evaluate()
+    with torch.no_grad():
+        per = [float(nn.functional.cross_entropy(toy(dict(pixel_values=b[0]["pixel_values"]))["outputs"], b[0]["label"]))
+               for b in batches]
+    assert abs(got["eval_loss"] - sum(per) / 3) < 1e-6                  # mean over BATCHES (engine.py:165), not over pixels
+    assert set(got) == {"eval_loss", "eval_aux_loss", "eval_mIOU_label"} and got["eval_mIOU_label"] == 0.25
+    assert seen["shapes"] == ((6, 5, 4, 4), (6, 4, 4))
+    assert "label" in batches[0][0]                                     # the caller's batch dict is left intact

@@ -393,6 +393,77 @@ def make_swin(R):
     print("swin:", [tuple(o.shape) for o in outs], "params without grad:", len(fx["no_grad"]), "full grads:", len(keep))
 
 
+def make_prompt(R):
+    """PromptDecoder(PromptLayer(512, 1024, 8, batch_first=True), 2) — the reference's construction at model/model.py:183
+    (post-norm, dropout 0.1 default, d_kv != d_model), here 2 layers deep — in EVAL mode (dropout inactive; identical
+    numbers to a dropout=0 training forward): forward + backward on tgt [2,150,512] (K text embeddings) and memory
+    [2,256,1024] (visual tokens).  Weights and inputs are regenerated from seeds (tests/golden_util.py), so the fixture
+    holds only the reference's outputs and gradients."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    from golden_util import make_weights, prompt_inputs
+    torch.manual_seed(31)
+    dec = R["rdec"].PromptDecoder(R["rdec"].PromptLayer(d_model=512, d_kv=1024, nhead=8, batch_first=True), num_layers=2)
+    named = dict(dec.named_parameters())
+    shapes = {k: list(v.shape) for k, v in named.items()}
+    w = make_weights(shapes, 32)
+    with torch.no_grad():
+        for k, p in named.items():
+            p.copy_(w[k])
+    dec.eval()
+    assert dec.layers[0].dropout.p == 0.1 and dec.layers[0].norm_first is False
+    tgt, mem, dout = prompt_inputs(33)
+    tgt.requires_grad_(True)
+    mem.requires_grad_(True)
+    out = dec(tgt=tgt, memory=mem)
+    out.backward(dout)
+    grads = {k: p.grad.detach().clone() for k, p in named.items()}
+    keep = ["layers.0.norm1.weight", "layers.1.norm3.weight", "layers.0.multihead_attn.in_proj_bias",
+            "layers.1.multihead_attn.out_proj.bias", "layers.1.self_attn.out_proj.weight",
+            "layers.0.multihead_attn.q_proj_weight"]
+    fx = dict(shapes={k: torch.tensor(v) for k, v in shapes.items()}, wseed=torch.tensor(32), iseed=torch.tensor(33),
+              out=out.detach().clone(), dtgt=tgt.grad.clone(), dmem_rows=mem.grad[:, ::4].clone(),
+              grad_stats={k: torch.stack([v.sum(), v.abs().sum()]) for k, v in grads.items()},
+              grad_full={k: grads[k] for k in keep})
+    torch.save(fx, OUT / "prompt_decoder.pt")
+    print("prompt_decoder: out", tuple(out.shape), "params", len(shapes), sorted(shapes)[:4])
+
+
+def make_clip_full(R):
+    """ImageEncoderCLIPFull.forward (model/encoder.py:67-68: last_hidden_state WITH the CLS row) at tiny dims: forward +
+    backward with an upstream gradient that is non-zero on the CLS row."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    from golden_util import clip_full_inputs, make_weights
+    torch.manual_seed(41)
+    vcfg = R["CLIPVisionConfig"](hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                                 image_size=64, patch_size=16)
+    enc = _bare(R["renc"].ImageEncoderCLIPFull)
+    enc.in_size, enc.patch_size = 64, 16
+    enc.enc = R["CLIPVisionModel"](vcfg)
+    named = dict(enc.named_parameters())
+    shapes = {k: list(v.shape) for k, v in named.items()}
+    w = make_weights(shapes, 42)
+    with torch.no_grad():
+        for k, p in named.items():
+            p.copy_(w[k])
+    enc.train()
+    pix, dout = clip_full_inputs(43)
+    out = enc(pixel_values=pix)
+    assert tuple(out.shape) == (2, 17, 128)
+    out.backward(dout)
+    grads = {k: (p.grad.detach().clone() if p.grad is not None else None) for k, p in named.items()}
+    keep = ["enc.embeddings.class_embedding", "enc.embeddings.position_embedding.weight",
+            "enc.embeddings.patch_embedding.weight", "enc.encoder.layers.0.self_attn.k_proj.weight",
+            "enc.encoder.layers.1.mlp.fc2.weight", "enc.pre_layrnorm.weight"]
+    fx = dict(shapes={k: torch.tensor(v) for k, v in shapes.items()}, wseed=torch.tensor(42), iseed=torch.tensor(43),
+              out=out.detach().clone(),
+              grad_stats={k: torch.stack([v.sum(), v.abs().sum()]) for k, v in grads.items() if v is not None},
+              no_grad=[k for k, v in grads.items() if v is None],
+              grad_full={k: grads[k] for k in keep})
+    torch.save(fx, OUT / "clip_full_tiny.pt")
+    print("clip_full: out", tuple(out.shape), "no grad:", fx["no_grad"])
+
+
+
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
     R = _ref_imports()
@@ -408,6 +479,10 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "swin":
         make_swin(R)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "prompt":
+        make_prompt(R)
+        make_clip_full(R)
+        return
     make_base_tiny(R)
     make_decoder_d96(R)
     make_ops(R)
@@ -415,6 +490,8 @@ def main():
     make_ftn(R)
     make_swin(R)
     make_contrastive(R)
+    make_prompt(R)
+    make_clip_full(R)
     # the reference's only data fixture on this path — copied as-is
     protos = torch.load(REF / "model" / "ade20k_prototypes.pt", weights_only=True)
     torch.save(protos.clone(), OUT / "ade20k_prototypes.pt")

@@ -14,6 +14,8 @@ def per_kernel(path, counter):
         if r["Counter_Name"] != counter:
             continue
         k = r["Kernel_Name"]
+        if "attn_" in k:    # vision / text / decoder launches of one attention kernel differ by grid: keep them apart
+            k = k + " grid=" + r.get("Grid_Size", "?")
         tot[k] += float(r["Counter_Value"]); n[k] += 1
     return tot, n
 
@@ -32,8 +34,8 @@ def main():
         w = csv.writer(f)
         w.writerow(["kernel", "launches", "fetch_size_kb_per_launch", "read_bytes_per_launch", "write_bytes_per_launch",
                     "hbm_bytes_per_launch"])
-        for r in rows[:40]:
-            w.writerow([r[0][:120], *r[1:]])
+        for r in rows[:60]:
+            w.writerow([r[0][:120] + (r[0][r[0].rfind(" grid="):] if " grid=" in r[0][120:] else ""), *r[1:]])
     dom = [r for r in rows if DOM in r[0]]
     n = sum(r[1] for r in dom)
     rd = sum(r[1] * r[3] for r in dom) / n
