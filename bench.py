@@ -94,11 +94,62 @@ class GemmTimer:
         return dict(launches=len(self.records), seconds=t, flops=fl)
 
 
+def host_cpu_info():
+    """What the host offers THIS process: CPU model string, logical CPUs in the affinity mask, the physical cores behind them
+    (unique (physical id, core id) pairs of /proc/cpuinfo) and the cgroup CPU quota, if any.  The thread count used for the
+    CPU baseline is min(physical cores in the mask, quota): SMT siblings and threads beyond the quota only add contention
+    (round 1 ran 128 torch threads on the box's share and its step times varied 2x)."""
+    import math
+    info = dict(model="unknown", logical=os.cpu_count() or 1)
+    try:
+        aff = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        aff = list(range(info["logical"]))
+    info["affinity"] = len(aff)
+    cores, cur = set(), {}
+    try:
+        for line in open("/proc/cpuinfo"):
+            if ":" not in line:
+                if cur and int(cur.get("processor", -1)) in aff:
+                    cores.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+                cur = {}
+                continue
+            k, v = (t.strip() for t in line.split(":", 1))
+            cur[k] = v
+            if k == "model name":
+                info["model"] = v
+        if cur and int(cur.get("processor", -1)) in aff:
+            cores.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+    except OSError:
+        pass
+    info["physical"] = len(cores) or len(aff)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    info["cgroup_quota"] = quota
+    info["threads"] = max(1, min(info["physical"], int(math.floor(quota)) if quota else info["physical"]))
+    return info
+
+
 def cpu_baseline(arch_kwargs, in_size, out_size, L, sample_images, steps):
     """The CPU oracle (oracle/ref_cpu.py: fp32 restatement of the reference path, pinned by golden vectors)
-    running the same train step on this box's host cores."""
+    running the same train step on this box's host cores — SURVEY.md §8d protocol: config-2 shapes at batch 4,
+    one warm-up step then >= 3 timed steps, threads = the physical cores this process may use (stated with the CPU model);
+    every step's wall time is listed."""
     from oracle import ref_cpu as O
     import lc2is_amd.nn as N
+    hw = host_cpu_info()
+    torch.set_num_threads(hw["threads"])
     torch.manual_seed(1024)
     m = N.BaseModelWithText(16, in_size, out_size, **arch_kwargs)
     sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
@@ -108,24 +159,32 @@ def cpu_baseline(arch_kwargs, in_size, out_size, L, sample_images, steps):
                     dec_heads=m.vision_decoder.layers[0].nhead, dec_layers=m.vision_decoder.num_layers)
     del m
     inputs, labels = synth_batch(sample_images, in_size, out_size, L, 2, "cpu")
-    cores = torch.get_num_threads()
-    O.train_step_sgd(sd, inputs, labels, cfg, 1e-5)  # warm-up
-    t0 = time.perf_counter()
-    for _ in range(steps):
+    times = []
+    for _ in range(steps + 1):          # step 0 = warm-up (allocator, thread pool, oneDNN primitive caches)
+        t0 = time.perf_counter()
         O.train_step_sgd(sd, inputs, labels, cfg, 1e-5)
-    dt = time.perf_counter() - t0
-    return dict(value=sample_images * steps / dt, unit="images/s", cores=cores, kind="port",
-                sample=f"{steps} train steps of batch {sample_images} at {in_size}x{in_size} (fp32 oracle, 1 warm-up)")
+        times.append(time.perf_counter() - t0)
+    dt = sum(times[1:])
+    return dict(value=sample_images * steps / dt, unit="images/s", cores=hw["threads"], kind="port",
+                sample=f"{steps} timed train steps of batch {sample_images} at {in_size}x{in_size} after 1 warm-up "
+                       f"(fp32 oracle, torch {torch.__version__} CPU kernels)",
+                cpu_model=hw["model"], physical_cores_available=hw["physical"], logical_cpus_in_affinity=hw["affinity"],
+                cgroup_cpu_quota=hw["cgroup_quota"], warmup_step_s=round(times[0], 3),
+                timed_step_s=[round(t, 3) for t in times[1:]])
 
 
 def pmc_traffic(args):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_final_pmc_hbm.json:
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this same command, gfx950 corrections applied).  Counters cannot be
-    read from inside the timed process, so the figure is the recorded one and only for the workload it was taken on."""
-    f = Path(__file__).resolve().parent / "profiles" / "r01_final_pmc_hbm.json"
-    if args.patch != 16 or args.batch != 32 or args.in_size != 512 or not f.exists():
-        return None
-    return json.loads(f.read_text())["hbm_bytes_per_launch"]
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary (profiles/r*_pmc_hbm.json, written
+    by tools/prof_pmc.sh + tools/pmc_sum.py: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command,
+    gfx950 corrections applied; the file names the commit it was taken at).  Counters cannot be read from inside the timed
+    process, so this is the recorded figure of that build, and only for the workload it was taken on.
+    Returns (bytes or None, source description or None)."""
+    prof = Path(__file__).resolve().parent / "profiles"
+    files = sorted(prof.glob("r*_pmc_hbm.json"))
+    if args.patch != 16 or args.batch != 32 or args.in_size != 512 or not files:
+        return None, None
+    rec = json.loads(files[-1].read_text())
+    return rec["hbm_bytes_per_launch"], f"profiles/{files[-1].name} @ {rec.get('commit', 'unrecorded commit')}"
 
 
 def main():
@@ -140,8 +199,8 @@ def main():
     ap.add_argument("--text-len", type=int, default=16)
     ap.add_argument("--optimizer", default="sgd")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-images", type=int, default=2)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-images", type=int, default=4, help="CPU-baseline batch (SURVEY.md §8d: 4)")
+    ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-baseline steps after one warm-up (SURVEY.md §8d: >= 3)")
     ap.add_argument("--graph", action="store_true", help="replay the step as one hipGraph (single GPU, SGD); one captured stream, so "
                     "slower than eager (795 vs 862 img/s): the step is GPU-bound and eager overlaps the text tower on a side stream")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI) | gloo (wiring tests on one GPU)")
@@ -240,7 +299,8 @@ def main():
             "final_loss": loss_val,
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_dma_kernel<256,256,2,4> (every launch of each 4th timed step)",
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(args),
+                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(args)[0],
+                         "traffic_source": pmc_traffic(args)[1],
                          "launches_per_step": gsum["launches"] / timed_steps, "hip_graph": use_graph,
                          "event_timed_steps": timed_steps,
                          "avg_launch_us": gsum["seconds"] / max(gsum["launches"], 1) * 1e6,

@@ -259,6 +259,12 @@ int lc2is_swin_attn_bwd(const void* qkv, int ld, const void* o, int ld_o, const 
                         int win_per_img, int nwx, int Hp, int Wp, int ws, int shift, int nH, int C, float scale,
                         void* workspace, size_t workspace_bytes, lc2is_stream_t stream);
 
+/* gradient of the relative_position_bias_table [T = (2 ws - 1)^2, nH] from dbias [nH, S*S]: dtable[t][h] = sum of
+ * dbias[h][p] over the pairs p = positions[offsets[t] .. offsets[t+1]) (the inverse of relative_position_index,
+ * modeling_swin.py:350-383), added in list order.  replaces: autograd of `table[index]` (index_put_ with accumulate). */
+int lc2is_swin_bias_table_grad(const float* dbias, const int* offsets, const int* positions, float* dtable, int nH, int SS,
+                               int T, int accumulate, lc2is_stream_t stream);
+
 /* ---- preprocessing in front of the path (evaluate.py:58-61, data/collator.py:82-91; Pillow inside transformers'
  * CLIPFeatureExtractor) — byte / integer work, bit-exact against Pillow --------------------------------------------
  * resample_u8: one separable 8-bit pass of PIL's ImagingResample over an HWC uint8 image along `axis` (1 = width,

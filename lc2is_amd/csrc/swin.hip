@@ -581,6 +581,21 @@ __global__ __launch_bounds__(64) void swin_attn_fwd_mfma_kernel(SwinAttnArgs a) 
   }
 }
 
+// Relative-position-bias TABLE gradient: dtable[t][h] = sum over the (query, key) pairs whose relative offset is t of
+// dbias[h][pair] (modeling_swin.py:371-383 gathers table[index] in the forward).  The pairs of every offset are listed in a
+// CSR index built once on the host (offsets[T+1], positions sorted by offset, ascending pair id inside an offset): one
+// thread per (t, h) adds its <= ws^2 terms in that fixed order, so the result is reproducible.
+__global__ __launch_bounds__(256) void swin_table_grad_kernel(const float* __restrict__ dbias, const int* __restrict__ offs,
+                                                               const int* __restrict__ pos, float* dtable, int nH, int SS,
+                                                               int T, int accumulate) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= T * nH) return;
+  const int t = i / nH, h = i % nH;
+  float s = 0.f;
+  for (int e = offs[t]; e < offs[t + 1]; ++e) s += dbias[(size_t)h * SS + pos[e]];
+  dtable[i] = accumulate ? dtable[i] + s : s;
+}
+
 // sum of the per-chunk partials in chunk order: 32 columns x 8 chunk groups per block, groups combined in a fixed order
 __global__ __launch_bounds__(256) void swin_dbias_reduce_kernel(const float* __restrict__ part, int nchunk, size_t n,
                                                                  float* out, int accumulate) {
@@ -720,5 +735,15 @@ extern "C" int lc2is_swin_attn_bwd(const void* qkv, int ld, const void* o, int l
   const size_t n = (size_t)nH * ws * ws * ws * ws;
   hipLaunchKernelGGL(swin_dbias_reduce_kernel, dim3((int)((n + 31) / 32)), dim3(256), 0, stream,
                      (const float*)workspace, nchunk_eff, n, dbias, accumulate_dbias);
+  return lc2is_check_launch();
+}
+
+extern "C" int lc2is_swin_bias_table_grad(const float* dbias, const int* offsets, const int* positions, float* dtable, int nH,
+                                          int SS, int T, int accumulate, lc2is_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!dbias || !offsets || !positions || !dtable) return LC2IS_ERR_NULL;
+  if (nH <= 0 || SS <= 0 || T <= 0) return LC2IS_ERR_SHAPE;
+  hipLaunchKernelGGL(swin_table_grad_kernel, dim3((T * nH + 255) / 256), dim3(256), 0, stream, dbias, offsets, positions,
+                     dtable, nH, SS, T, accumulate);
   return lc2is_check_launch();
 }

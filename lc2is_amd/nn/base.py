@@ -259,12 +259,25 @@ class ParamArena:
             self.attach_grads()
 
     def finalize_grads(self):
-        """After backward: parameters the graph never reached (e.g. CLIP's post_layernorm) get a zero gradient
-        so the flat buffer is fully defined for the fused optimizer / all-reduce."""
-        for p in self.params:
+        """After backward: parameters without a gradient — frozen ones (requires_grad=False, e.g. the reference's frozen
+        text towers, model/model.py:115-117) and ones the graph never reached (CLIP's post_layernorm) — get a zero
+        gradient so the flat buffer is fully defined for the all-reduce.  Returns the LIVE segments [(lo, hi)] of the
+        arena (maximal runs of parameters that did receive a gradient, alignment padding included): torch.optim skips
+        parameters whose grad is None, so an optimizer with weight decay must only touch these."""
+        live, run = [], None
+        for p, o in zip(self.params, self.offsets):
+            end = o + (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
             if p.grad is None:
                 p._lc2is_grad.zero_()
                 p.grad = p._lc2is_grad
+                if run is not None:
+                    live.append(run)
+                    run = None
+            else:
+                run = (run[0], end) if run is not None else (o, end)
+        if run is not None:
+            live.append(run)
+        return live
 
     def module_range(self, module: nn.Module):
         lo, hi = None, None

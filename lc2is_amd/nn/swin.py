@@ -233,11 +233,14 @@ class SwinTransformer(HipModule):
         idx = getattr(self, "_rel_idx", None)
         if idx is None or idx.device != dev:      # built once: no host-to-device copy per refresh (hipGraph-capturable)
             idx = self._rel_idx = relative_position_index(ws).to(dev)
-        if self._onehot is None or self._onehot.device != dev:
+        if self._onehot is None or self._onehot[0].device != dev:
+            # inverse of the index (init-time host code): for every table row t, the (query, key) pairs that read it
             T = (2 * ws - 1) ** 2
-            oh = torch.zeros(T, S * S, dtype=torch.float32, device=dev)
-            oh[idx, torch.arange(S * S, device=dev)] = 1.0
-            self._onehot = oh
+            host = relative_position_index(ws)
+            order = torch.sort(host, stable=True).indices                   # pairs grouped by t, ascending pair id inside
+            offs = torch.zeros(T + 1, dtype=torch.int64)
+            offs[1:] = torch.cumsum(torch.bincount(host, minlength=T), 0)
+            self._onehot = (offs.to(torch.int32).to(dev), order.to(torch.int32).to(dev))
         for st, ss in zip(self._stages(), self._sh["stages"]):
             for b, s in zip(st.blocks, ss["blocks"]):
                 t = b.attention.relative_position_bias.relative_position_bias_table.detach()
@@ -397,8 +400,7 @@ class SwinTransformer(HipModule):
                           mp["Hp"], mp["Wp"], ws, shift, nH, 32 ** -0.5, dbias=dbias, dqkv=dqkv[:, :3 * C])
         if dbias is not None:
             gt, acc = grad_buf(table)
-            dt = torch.mm(self._onehot, dbias.view(nH, S * S).t())                                # [T, nH], fixed summation order
-            gt.add_(dt) if acc else gt.copy_(dt)
+            ops.swin_bias_table_grad(dbias, self._onehot[0], self._onehot[1], gt, accumulate=acc)   # [T, nH], fixed order
         self._qkv_wgrad(dqkv[:, :3 * C], sv["win16"], at, C)
         dwin16, _, _ = ops.gemm_nt(dqkv, s["wqkvT"][:C], None)                                     # [Mw, C]
         dh16 = ops.rows_gather(dwin16, mp["inv"])                                                 # [M, C] bf16

@@ -67,6 +67,7 @@ _ARGTYPES = {
     "lc2is_gather2d_u8": [_P, _I, _I, _I, _P, _I, _I, _P, _P, _P],
     "lc2is_crop_lut": [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "lc2is_swin_attn_fwd": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P],
+    "lc2is_swin_bias_table_grad": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "lc2is_swin_attn_bwd_workspace_bytes": [_I, _I, _I],
     "lc2is_swin_attn_bwd": [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F,
                             _P, _Z, _P],
@@ -751,6 +752,22 @@ def swin_attn_bwd(qkv, o, do, lse, bias, nwin: int, win_per_img: int, nwx: int, 
 
 
 # ---- preprocessing (uint8 images) ---------------------------------------------------------------------------------
+def swin_bias_table_grad(dbias: torch.Tensor, offsets: torch.Tensor, positions: torch.Tensor, dtable: torch.Tensor,
+                         accumulate: bool = False):
+    """dtable [T, nH] (+)= sum of dbias [nH, S, S] over the pairs of each relative offset (CSR index, fixed order)."""
+    _chk(dbias, torch.float32, "dbias", 3); _chk(dtable, torch.float32, "dtable", 2)
+    _chk(offsets, torch.int32, "offsets", 1); _chk(positions, torch.int32, "positions", 1)
+    nH, S, S2 = dbias.shape
+    T = dtable.shape[0]
+    if S2 != S or dtable.shape[1] != nH or offsets.numel() != T + 1 or positions.numel() != S * S \
+            or not dbias.is_contiguous() or not dtable.is_contiguous():
+        raise RuntimeError("lc2is_amd.swin_bias_table_grad: shape mismatch")
+    rc = _fn("lc2is_swin_bias_table_grad")(_ptr(dbias), _ptr(offsets), _ptr(positions), _ptr(dtable), nH, S * S, T,
+                                           int(accumulate), _stream())
+    _lib.check(rc, "swin_bias_table_grad")
+    return dtable
+
+
 def _u8(t, name):
     if not t.is_cuda or t.dtype != torch.uint8 or t.dim() != 3 or not t.is_contiguous():
         raise RuntimeError(f"lc2is_amd: {name} must be a contiguous uint8 HWC tensor on a HIP device")

@@ -54,17 +54,24 @@ class TrainStep:
             self.reducer.begin_step()
         loss = self.model.forward_loss(inputs, labels, self.ignore_index)
         loss.backward()
-        arena.finalize_grads()
+        live = arena.finalize_grads()
         gscale = 1.0
         if self.reducer is not None:
             self.reducer.finish_step()
             gscale = 1.0 / self.reducer.world_size
         self.t += 1
-        if self.kind == "sgd":
-            ops.sgd_step(arena.flat, arena.grad, self.mom, self.lr, self.momentum, self.weight_decay, gscale)
-        else:
-            ops.adamw_step(arena.flat, arena.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps,
-                           self.weight_decay, self.t, gscale)
+        # One fused launch over the whole arena; a zero gradient leaves a parameter untouched unless weight decay is on —
+        # then, like torch.optim (which skips parameters whose grad is None), only the live segments are updated so that
+        # frozen / unreached parameters stay bit-identical.
+        segs = [(0, arena.numel)] if (self.weight_decay == 0.0 or live == [(0, arena.numel)]) else live
+        for lo, hi in segs:
+            sl = slice(lo, hi)
+            if self.kind == "sgd":
+                ops.sgd_step(arena.flat[sl], arena.grad[sl], None if self.mom is None else self.mom[sl], self.lr,
+                             self.momentum, self.weight_decay, gscale)
+            else:
+                ops.adamw_step(arena.flat[sl], arena.grad[sl], self.m[sl], self.v[sl], self.lr, self.betas[0],
+                               self.betas[1], self.eps, self.weight_decay, self.t, gscale)
         for m in self._hip_modules:
             m.invalidate_shadows()
         return loss.detach()

@@ -170,3 +170,20 @@ def test_evaluator_host_logic_matches_engine_eval_loop():
     assert set(got) == {"eval_loss", "eval_aux_loss", "eval_mIOU_label"} and got["eval_mIOU_label"] == 0.25
     assert seen["shapes"] == ((6, 5, 4, 4), (6, 4, 4))
     assert "label" in batches[0][0]                                     # the caller's batch dict is left intact
+
+
+def test_product_path_has_no_library_math():
+    """PyTorch is plumbing (memory, streams, autograd between modules), never the math of the path: no matmul-family call
+    may appear under lc2is_amd/ except the init-time (host, load-time) position-table resize of model/encoder.py:32-44."""
+    import re
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent / "lc2is_amd"
+    pat = re.compile(r"torch\.(mm|matmul|bmm|addmm|baddbmm|einsum|tensordot)\b|F\.(linear|conv2d|scaled_dot_product_attention)\b"
+                     r"|nn\.functional\.(linear|conv2d|scaled_dot_product_attention)\b")
+    hits = []
+    for f in sorted(root.rglob("*.py")):
+        for n, line in enumerate(f.read_text().splitlines(), 1):
+            code = line.split("#", 1)[0]
+            if pat.search(code):
+                hits.append(f"{f.relative_to(root)}:{n}")
+    assert hits == ["nn/clip.py:310"], hits

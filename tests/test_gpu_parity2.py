@@ -332,3 +332,33 @@ def test_fused_head_gradients_with_ignored_labels(dev, ignore_index):
     N.CrossEntropyLoss(ignore_index=ignore_index)(m(dinputs)["outputs"], labels.to(dev)).backward()
     for k in keys:
         assert _rel(named[k].grad, fused[k]) < 2e-2, k
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# optimizer semantics for parameters without a gradient: torch.optim skips them, weight decay included
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("opt", ["sgd", "adamw"])
+def test_frozen_parameters_are_untouched_under_weight_decay(dev, opt):
+    from lc2is_amd.step import TrainStep
+    from test_gpu_edges import _tiny
+    m, sd, cfg, _ = _tiny(dev)
+    for p in m.text_encoder.parameters():                                   # the reference freezes its text towers so
+        p.requires_grad = False                                             # (model/model.py:115-117, ftn.py:32-34)
+    g = torch.Generator().manual_seed(5)
+    inputs = dict(pixel_values=torch.randn(2, 3, 64, 64, generator=g).to(dev),
+                  input_ids=torch.randint(1, 500, (2, 6), generator=g).to(dev),
+                  attention_mask=torch.ones(2, 6, dtype=torch.long, device=dev))
+    labels = torch.randint(0, 151, (2, 16, 16), generator=g).to(dev)
+    ts = TrainStep(m, optimizer=opt, lr=1e-2, weight_decay=0.1)
+    before = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    ts.step(inputs, labels)
+    ts.step(inputs, labels)
+    after = m.state_dict()
+    untouched = [k for k in before if k.startswith("text_encoder.") or "post_layernorm" in k]
+    assert len(untouched) > 10
+    for k in untouched:                                                     # frozen tower + the unreached post_layernorm
+        assert torch.equal(after[k], before[k]), k
+    moved = [k for k in before if k.startswith("vision_decoder.") and not torch.equal(after[k], before[k])]
+    assert len(moved) > 5                                                   # the trainable parameters did move (and decay)
+    w0, w1 = before["pixel_patch.visual.weight"], after["pixel_patch.visual.weight"]
+    assert float((w1 - w0).abs().max()) > 0

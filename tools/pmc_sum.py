@@ -1,5 +1,5 @@
 """HBM bytes per launch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over bench.py.
-usage: pmc_sum.py <fetch counter_collection.csv> <write counter_collection.csv> <out prefix>
+usage: pmc_sum.py <fetch counter_collection.csv> <write counter_collection.csv> <out prefix> [commit]
 Writes <prefix>_hbm_per_kernel.csv and <prefix>_hbm.json (the dominant kernel: every instantiation of
 gemm_nt_dma_kernel<256, 256, 2, 4, 0, *> aggregated).  Corrections per MI355X_MICROARCH.md (HBM section): FETCH_SIZE is KB
 and tallies 128-B requests at 64 B on gfx950 -> bytes = 2 x 1000 x FETCH_SIZE; WRITE_SIZE is KB, exact."""
@@ -40,7 +40,8 @@ def main():
     n = sum(r[1] for r in dom)
     rd = sum(r[1] * r[3] for r in dom) / n
     wr = sum(r[1] * r[4] for r in dom) / n
-    out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 2 --warmup 1 "
+    out = {"commit": sys.argv[4] if len(sys.argv) > 4 else "unrecorded",
+           "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 2 --warmup 1 "
                       "--no-cpu-baseline (two separate passes, tools/prof_pmc.sh)",
            "corrections": "FETCH_SIZE is KB and tallies 128-B requests at 64 B on gfx950: bytes = 2 x 1000 x FETCH_SIZE; "
                           "WRITE_SIZE KB exact (MI355X_MICROARCH.md, HBM section)",
