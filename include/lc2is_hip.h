@@ -148,6 +148,37 @@ int lc2is_attention_bwd(const void* Q, int ldq, const void* K, int ldk, const vo
                         int lddk, void* dV, int lddv, const float* lse2, float* delta, const float* kbias,
                         int B, int H, int Sq, int Sk, int D, float scale, int causal, lc2is_stream_t stream);
 
+/* The same two operators with dropout on the attention probabilities (training mode of torch's
+ * multi_head_attention_forward, dropout_p = the layer's `dropout`: torch:nn/functional.py:6206, reached from
+ * PromptLayer model/decoder.py:24-28, the SR layers model/hierarchical.py:174-225 / model/decoder.py:113-134 and
+ * nn.TransformerDecoderLayer at model/ftn.py:135).  No mask is stored: keep(seed, row=(b*H+h)*Sq+q, col=key) is a
+ * counter-based hash evaluated in the forward and again in both backward kernels (csrc/common.h); survivors are scaled
+ * by 1/(1-p).  The stream is this library's, not torch's Philox stream; lc2is_dropout_mask exports it for tests. */
+int lc2is_attention_fwd_dropout(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O,
+                                int ldo, float* lse2, const float* kbias, int B, int H, int Sq, int Sk, int D,
+                                float scale, int causal, float p_drop, unsigned long long seed, lc2is_stream_t stream);
+int lc2is_attention_bwd_dropout(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
+                                const void* O, int ldo, const void* dO, int lddo, void* dQ, int lddq, void* dK,
+                                int lddk, void* dV, int lddv, const float* lse2, float* delta, const float* kbias,
+                                int B, int H, int Sq, int Sk, int D, float scale, int causal, float p_drop,
+                                unsigned long long seed, lc2is_stream_t stream);
+
+/* ---- dropout / drop-path (training mode), mask never materialised ------------------------------------------------
+ * dropout_rows_f32: y[m][c] = resid[m][c] + keep * x[m][c] / (1-p)   (resid optional; fp32 and / or bf16 output).
+ *   rows_per_sample == 0: one Bernoulli(1-p) decision per element, coordinate (m, c) — nn.Dropout on a branch output
+ *   (dropout1/2/3 of torch's Transformer layers) and, applied to a gradient with the forward's seed, its backward.
+ *   rows_per_sample > 0: one decision per SAMPLE (row m belongs to sample m / rows_per_sample) — hf SwinDropPath
+ *   (modeling_swin.py:280-302) and its backward.
+ * dropout_rows_bf16: the same per-element form on bf16 (the dropout between activation and linear2).
+ * dropout_mask: out[r][c] = keep(seed, r, c) as bytes — test / debug export of the decisions, never on the product path. */
+int lc2is_dropout_rows_f32(const float* x, int ldx, const float* resid, int ldr, float* y32, int ldy, void* y16,
+                           int ldy16, int M, int C, int rows_per_sample, float p, unsigned long long seed,
+                           lc2is_stream_t stream);
+int lc2is_dropout_rows_bf16(const void* x, int ldx, void* y, int ldy, int M, int C, float p, unsigned long long seed,
+                            lc2is_stream_t stream);
+int lc2is_dropout_mask(unsigned char* out, long rows, int cols, float p, unsigned long long seed, lc2is_stream_t stream);
+
+
 /* ---- glue (all single-pass, HBM-bound) --------------------------------------------------------------
  * Refresh every bf16 weight shadow from the fp32 master copy in ONE launch: `descs` is a DEVICE array of
  * ndesc descriptors ordered by tile_start; total_tiles = sum of tile counts.  K % 4 == 0 always, N % 4 == 0

@@ -34,6 +34,7 @@ struct AttnBwdArgs {
   int B, H, Sq, Sk;
   float scale, scale_log2;
   int causal;
+  DropCfg drop;        // attention-probability dropout of the forward (DROP instantiations only)
 };
 
 constexpr float LOG2E = 1.44269504088896341f;
@@ -83,7 +84,10 @@ __device__ __forceinline__ float dot8(const i32x4_t& a, const i32x4_t& b) {
 // ------------------------------------------------------------------------------------------------------
 // (1) dQ kernel: grid (ceil(Sq/128), H, B), 4 waves x 32 queries; loops over 64-key tiles.
 // ------------------------------------------------------------------------------------------------------
-template <int D>
+// DROP (both kernels): the forward dropped attention probabilities, O = (keep∘P / (1-p)) V.  Then dP = keep∘(dO V^T) / (1-p),
+// dV = (keep∘P / (1-p))^T dO, dS = P∘(dP − δ) with the UNDROPPED P and δ = rowsum(dO∘O) as before; keep is re-evaluated
+// from the same (row, key) coordinates as in attention_fwd.hip.
+template <int D, bool DROP = false>
 __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dq_kernel(AttnBwdArgs p) {
   using I = Img<D>;
   constexpr int NKS = D / 16, NDT = D / 32, CH = I::CH, NCH = I::NCH;
@@ -99,6 +103,7 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dq_kernel(Att
   const bool qok = qrow < p.Sq;
   const bool wave_active = (int)(bx * 128 + wid * 32) < p.Sq;   // wave-uniform
   const float INF = __builtin_inff();
+  const unsigned drop_rh = DROP ? drop_row_hash(p.drop, (unsigned)((b * p.H + head) * p.Sq + qrow)) : 0u;
 
   int nkt = (p.Sk + 63) / 64;
   if (p.causal) {
@@ -217,6 +222,13 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dq_kernel(Att
         st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st, 0, 0, 0);
         dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[s], dpt, 0, 0, 0);
       }
+      if constexpr (DROP) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const unsigned key = (unsigned)(kt * 64 + 32 * t + 8 * (r >> 2) + 4 * hh + (r & 3));
+          dpt[r] = drop_keep(p.drop, drop_rh, key) ? dpt[r] * p.drop.inv_keep : 0.f;
+        }
+      }
       if (!masked) {  // interior tile: one fma + exp + sub + mul per score, no branches
         const float neg_lse = -lse;
 #pragma unroll
@@ -273,11 +285,11 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dq_kernel(Att
 // ------------------------------------------------------------------------------------------------------
 // (2) dK/dV kernel: grid (ceil(Sk/128), H, B), 4 waves x 32 keys; loops over 64-query tiles.
 // ------------------------------------------------------------------------------------------------------
-template <int D>
+template <int D, bool DROP = false>
 __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
   using I = Img<D>;
   constexpr int NKS = D / 16, NDT = D / 32, CH = I::CH, NCH = I::NCH;
-  constexpr int STAGE = 2 * I::TILE + 512;  // Q image, dO image, 64 lse2, 64 delta
+  constexpr int STAGE = 2 * I::TILE + 768;  // Q image, dO image, 64 lse2, 64 delta, 64 dropout row hashes
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -336,6 +348,9 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(A
       } else {
         rstat = (q < p.Sq) ? p.delta[si] : 0.f;
       }
+    } else if (DROP && tid < 192) {   // 128..191: the row half of the dropout hash of query q
+      const int q = qt * 64 + (tid & 63);
+      rstat = __builtin_bit_cast(float, drop_row_hash(p.drop, (unsigned)((b * p.H + head) * p.Sq + q)));
     }
   };
   auto lstore = [&](char* stage) {
@@ -344,7 +359,7 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(A
       *(i32x4_t*)(stage + t_lds[i]) = rq[i];
       *(i32x4_t*)(stage + I::TILE + t_lds[i]) = rg[i];
     }
-    if (tid < 128) *(float*)(stage + 2 * I::TILE + tid * 4) = rstat;
+    if (tid < (DROP ? 192 : 128)) *(float*)(stage + 2 * I::TILE + tid * 4) = rstat;
   };
 
   const int q4 = (lane >> 2) & 3, p4 = lane & 3, cg = (lane >> 4) & 1;
@@ -398,11 +413,20 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(A
       for (int c = 0; c < 4; ++c) {
         const f32x4_t l4 = *(const f32x4_t*)(lsev + 32 * u + 8 * c + 4 * hh);
         const f32x4_t d4 = *(const f32x4_t*)(delv + 32 * u + 8 * c + 4 * hh);
+        float keep4[4] = {1.f, 1.f, 1.f, 1.f};
+        if constexpr (DROP) {
+          const i32x4_t rh4 = *(const i32x4_t*)(delv + 64 + 32 * u + 8 * c + 4 * hh);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            keep4[j] = drop_keep(p.drop, (unsigned)rh4[j], (unsigned)kcol) ? p.drop.inv_keep : 0.f;
+            dp[4 * c + j] *= keep4[j];
+          }
+        }
         if (!diag) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sa[4 * c + j], p.scale_log2, bias) - l4[j]);
-            sa[4 * c + j] = pr;
+            sa[4 * c + j] = DROP ? pr * keep4[j] : pr;     // dV takes the dropped probabilities
             dp[4 * c + j] = pr * (dp[4 * c + j] - d4[j]);
           }
         } else {
@@ -412,7 +436,7 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(A
             const int q = qt * 64 + 32 * u + 8 * c + 4 * hh + j;
             if (kcol > q) s2 = -INF;
             const float pr = __builtin_amdgcn_exp2f(s2);
-            sa[4 * c + j] = pr;
+            sa[4 * c + j] = DROP ? pr * keep4[j] : pr;
             dp[4 * c + j] = pr * (dp[4 * c + j] - d4[j]);
           }
         }
@@ -455,12 +479,12 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(A
   }
 }
 
-template <int D>
+template <int D, bool DROP = false>
 int launch_attn_bwd(const AttnBwdArgs& a, hipStream_t stream) {
   using I = Img<D>;
-  constexpr int LDS_DQ = 2 * (2 * I::TILE + 256), LDS_KV = 2 * (2 * I::TILE + 512);
-  auto k1 = attn_bwd_dq_kernel<D>;
-  auto k2 = attn_bwd_dkdv_kernel<D>;
+  constexpr int LDS_DQ = 2 * (2 * I::TILE + 256), LDS_KV = 2 * (2 * I::TILE + 768);
+  auto k1 = attn_bwd_dq_kernel<D, DROP>;
+  auto k2 = attn_bwd_dkdv_kernel<D, DROP>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ) != hipSuccess ||
@@ -477,11 +501,11 @@ int launch_attn_bwd(const AttnBwdArgs& a, hipStream_t stream) {
 
 }  // namespace
 
-extern "C" int lc2is_attention_bwd(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
-                                   const void* O, int ldo, const void* dO, int lddo, void* dQ, int lddq,
-                                   void* dK, int lddk, void* dV, int lddv, const float* lse2, float* delta,
-                                   const float* kbias, int B, int H, int Sq, int Sk, int D, float scale,
-                                   int causal, lc2is_stream_t stream_) {
+static int attention_bwd_impl(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
+                              const void* O, int ldo, const void* dO, int lddo, void* dQ, int lddq,
+                              void* dK, int lddk, void* dV, int lddv, const float* lse2, float* delta,
+                              const float* kbias, int B, int H, int Sq, int Sk, int D, float scale,
+                              int causal, float p_drop, unsigned long long seed, lc2is_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!Q || !K || !V || !O || !dO || !dQ || !dK || !dV || !lse2 || !delta) return LC2IS_ERR_NULL;
   if (B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0) return LC2IS_ERR_SHAPE;
@@ -491,6 +515,7 @@ extern "C" int lc2is_attention_bwd(const void* Q, int ldq, const void* K, int ld
   if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 8 || lddo % 8 || lddq % 4 || lddk % 4 || lddv % 4)
     return LC2IS_ERR_SHAPE;
   if (causal && Sq != Sk) return LC2IS_ERR_UNSUPPORTED;
+  if (!(p_drop >= 0.f && p_drop < 1.f)) return LC2IS_ERR_UNSUPPORTED;
   const double lim = 2147483648.0;
   if ((double)B * (Sq + 64) * ldq * 2.0 >= lim || (double)B * (Sq + 64) * lddo * 2.0 >= lim ||
       (double)B * (Sq + 64) * ldo * 2.0 >= lim || (double)B * (Sk + 64) * ldk * 2.0 >= lim ||
@@ -498,11 +523,38 @@ extern "C" int lc2is_attention_bwd(const void* Q, int ldq, const void* K, int ld
     return LC2IS_ERR_UNSUPPORTED;
   AttnBwdArgs a{(const bf16_t*)Q, ldq, (const bf16_t*)K, ldk, (const bf16_t*)V, ldv, (const bf16_t*)O, ldo,
                 (const bf16_t*)dO, lddo, (bf16_t*)dQ, lddq, (bf16_t*)dK, lddk, (bf16_t*)dV, lddv, lse2, delta,
-                kbias, B, H, Sq, Sk, scale, scale * LOG2E, causal};
+                kbias, B, H, Sq, Sk, scale, scale * LOG2E, causal, make_drop_cfg(p_drop, seed)};
+  if (a.drop.thr) {
+    if ((double)B * H * Sq >= 4294967296.0) return LC2IS_ERR_UNSUPPORTED;
+    switch (D) {
+      case 64: return launch_attn_bwd<64, true>(a, stream);
+      case 96: return launch_attn_bwd<96, true>(a, stream);
+      case 128: return launch_attn_bwd<128, true>(a, stream);
+      default: return LC2IS_ERR_UNSUPPORTED;
+    }
+  }
   switch (D) {
     case 64: return launch_attn_bwd<64>(a, stream);
     case 96: return launch_attn_bwd<96>(a, stream);
     case 128: return launch_attn_bwd<128>(a, stream);
     default: return LC2IS_ERR_UNSUPPORTED;
   }
+}
+
+extern "C" int lc2is_attention_bwd(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
+                                   const void* O, int ldo, const void* dO, int lddo, void* dQ, int lddq,
+                                   void* dK, int lddk, void* dV, int lddv, const float* lse2, float* delta,
+                                   const float* kbias, int B, int H, int Sq, int Sk, int D, float scale,
+                                   int causal, lc2is_stream_t stream) {
+  return attention_bwd_impl(Q, ldq, K, ldk, V, ldv, O, ldo, dO, lddo, dQ, lddq, dK, lddk, dV, lddv, lse2, delta, kbias, B, H,
+                            Sq, Sk, D, scale, causal, 0.f, 0ULL, stream);
+}
+
+extern "C" int lc2is_attention_bwd_dropout(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
+                                           const void* O, int ldo, const void* dO, int lddo, void* dQ, int lddq,
+                                           void* dK, int lddk, void* dV, int lddv, const float* lse2, float* delta,
+                                           const float* kbias, int B, int H, int Sq, int Sk, int D, float scale,
+                                           int causal, float p_drop, unsigned long long seed, lc2is_stream_t stream) {
+  return attention_bwd_impl(Q, ldq, K, ldk, V, ldv, O, ldo, dO, lddo, dQ, lddq, dK, lddk, dV, lddv, lse2, delta, kbias, B, H,
+                            Sq, Sk, D, scale, causal, p_drop, seed, stream);
 }

@@ -33,6 +33,7 @@ struct AttnFwdArgs {
   int B, H, Sq, Sk;
   float scale_log2;     // softmax scale * log2(e)
   int causal;
+  DropCfg drop;         // attention-probability dropout (DROP instantiations only)
 };
 
 template <int D> struct AttnCfg {
@@ -55,7 +56,10 @@ __device__ __forceinline__ bf16x8_t tr_frag2(const char* base, int addr_lo, int 
 
 // DBG (diagnostic builds, LC2IS_ATTN_DBG; results are WRONG by design): bit 0 = no softmax arithmetic, bit 1 = K / V^T fragments
 // read from LDS once before the loop, bit 2 = no global loads / LDS stores inside the loop, bit 3 = no P.V MFMAs
-template <int D, int DBG = 0>
+// DROP: dropout on the attention probabilities (torch multi_head_attention_forward dropout_p in training mode,
+// torch:nn/functional.py:6206): the normaliser l sums the UNDROPPED probabilities, O accumulates keep * P / (1 - p);
+// coordinate of a score = (row (b*H + h)*Sq + q, column key), so the backward kernels regenerate the same decisions.
+template <int D, int DBG = 0, bool DROP = false>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnFwdArgs p) {
   using Cfg = AttnCfg<D>;
   constexpr int KS = Cfg::KS, VS = Cfg::VS, CH = Cfg::CH, NCH = Cfg::NCH;
@@ -73,6 +77,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnFwdArgs p) {
   const int qrow = q0 + l31;
   const bool wave_active = q0 < p.Sq;   // wave-uniform (wid comes from threadIdx.x >> 6)
   const float NEG_INF = -__builtin_inff();
+  const unsigned drop_rh = DROP ? drop_row_hash(p.drop, (unsigned)((b * p.H + head) * p.Sq + qrow)) : 0u;
 
   int nkt = (p.Sk + 63) / 64;
   if (p.causal) {
@@ -234,6 +239,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnFwdArgs p) {
         }
     }
     l_run = l_run * alpha + psum;
+    if constexpr (DROP) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const unsigned key = (unsigned)(kt * 64 + 32 * t + 8 * (r >> 2) + 4 * hh + (r & 3));
+          st[t][r] = drop_keep(p.drop, drop_rh, key) ? st[t][r] * p.drop.inv_keep : 0.f;
+        }
+    }
     if (__any(alpha != 1.f)) {  // lazy rescale: once the running max has settled nothing is multiplied
 #pragma unroll
       for (int d = 0; d < NDT; ++d)
@@ -284,10 +298,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnFwdArgs p) {
   }
 }
 
-template <int D, int DBG = 0>
+template <int D, int DBG = 0, bool DROP = false>
 int launch_attn_fwd(const AttnFwdArgs& a, hipStream_t stream) {
   using Cfg = AttnCfg<D>;
-  auto kern = attn_fwd_kernel<D, DBG>;
+  auto kern = attn_fwd_kernel<D, DBG, DROP>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Cfg::STAGE) !=
@@ -303,20 +317,31 @@ int launch_attn_fwd(const AttnFwdArgs& a, hipStream_t stream) {
 
 }  // namespace
 
-extern "C" int lc2is_attention_fwd(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
-                                   void* O, int ldo, float* lse2, const float* kbias, int B, int H, int Sq,
-                                   int Sk, int D, float scale, int causal, lc2is_stream_t stream_) {
+static int attention_fwd_impl(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
+                              void* O, int ldo, float* lse2, const float* kbias, int B, int H, int Sq,
+                              int Sk, int D, float scale, int causal, float p_drop, unsigned long long seed,
+                              lc2is_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!Q || !K || !V || !O) return LC2IS_ERR_NULL;
   if (B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0) return LC2IS_ERR_SHAPE;
   if (ldq < H * D || ldk < H * D || ldv < H * D || ldo < H * D || ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4)
     return LC2IS_ERR_SHAPE;
   if (causal && Sq != Sk) return LC2IS_ERR_UNSUPPORTED;
+  if (!(p_drop >= 0.f && p_drop < 1.f)) return LC2IS_ERR_UNSUPPORTED;
   if ((double)B * Sq * ldq * 2.0 >= 2147483648.0 || (double)B * (Sk + 64) * ldk * 2.0 >= 2147483648.0 ||
       (double)B * (Sk + 64) * ldv * 2.0 >= 2147483648.0)
     return LC2IS_ERR_UNSUPPORTED;
   AttnFwdArgs a{(const bf16_t*)Q, ldq, (const bf16_t*)K, ldk, (const bf16_t*)V, ldv, (bf16_t*)O, ldo, lse2,
-                kbias, B, H, Sq, Sk, scale * 1.44269504088896341f, causal};
+                kbias, B, H, Sq, Sk, scale * 1.44269504088896341f, causal, make_drop_cfg(p_drop, seed)};
+  if (a.drop.thr) {
+    if ((double)B * H * Sq >= 4294967296.0) return LC2IS_ERR_UNSUPPORTED;   // 32-bit row coordinate of the RNG
+    switch (D) {
+      case 64: return launch_attn_fwd<64, 0, true>(a, stream);
+      case 96: return launch_attn_fwd<96, 0, true>(a, stream);
+      case 128: return launch_attn_fwd<128, 0, true>(a, stream);
+      default: return LC2IS_ERR_UNSUPPORTED;
+    }
+  }
   switch (D) {
     case 64: {
       static const int dbg = getenv("LC2IS_ATTN_DBG") ? atoi(getenv("LC2IS_ATTN_DBG")) : 0;
@@ -335,4 +360,18 @@ extern "C" int lc2is_attention_fwd(const void* Q, int ldq, const void* K, int ld
     case 128: return launch_attn_fwd<128>(a, stream);
     default: return LC2IS_ERR_UNSUPPORTED;
   }
+}
+
+extern "C" int lc2is_attention_fwd(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
+                                   void* O, int ldo, float* lse2, const float* kbias, int B, int H, int Sq,
+                                   int Sk, int D, float scale, int causal, lc2is_stream_t stream) {
+  return attention_fwd_impl(Q, ldq, K, ldk, V, ldv, O, ldo, lse2, kbias, B, H, Sq, Sk, D, scale, causal, 0.f, 0ULL, stream);
+}
+
+extern "C" int lc2is_attention_fwd_dropout(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
+                                           void* O, int ldo, float* lse2, const float* kbias, int B, int H, int Sq,
+                                           int Sk, int D, float scale, int causal, float p_drop,
+                                           unsigned long long seed, lc2is_stream_t stream) {
+  return attention_fwd_impl(Q, ldq, K, ldk, V, ldv, O, ldo, lse2, kbias, B, H, Sq, Sk, D, scale, causal, p_drop, seed,
+                            stream);
 }

@@ -70,6 +70,35 @@ __device__ __forceinline__ float wave_max(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// ---- counter-based dropout RNG ------------------------------------------------------------------------------------
+// keep(seed, r, c) is a pure function of a 64-bit seed and a (row, column) coordinate: the forward and the backward
+// kernels of a dropout site evaluate it again instead of storing a mask (nn.Dropout / F.dropout / the attention-probability
+// dropout of torch's multi_head_attention_forward and hf SwinDropPath are re-stated this way; the stream differs from
+// torch's Philox stream, the distribution — Bernoulli(1 - p), survivors scaled by 1/(1 - p) — is the same).
+// mix32 = "lowbias32" (two multiplies, three xor-shifts; full avalanche).  The row half is hoisted wherever the row is
+// fixed per lane.  16 bits decide: keep iff bits >= thr, thr = round(p * 65536).
+struct DropCfg {
+  unsigned seed_lo, seed_hi, thr;   // thr == 0: dropout off
+  float inv_keep;                   // 1 / (1 - p)
+};
+__device__ __forceinline__ unsigned mix32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ unsigned drop_row_hash(const DropCfg& d, unsigned r) { return mix32(r + d.seed_lo); }
+__device__ __forceinline__ bool drop_keep(const DropCfg& d, unsigned row_hash, unsigned c) {
+  return (mix32(row_hash ^ (c + d.seed_hi)) & 0xffffU) >= d.thr;
+}
+static inline DropCfg make_drop_cfg(float p, unsigned long long seed) {
+  DropCfg d;
+  d.seed_lo = (unsigned)(seed & 0xffffffffULL);
+  d.seed_hi = (unsigned)(seed >> 32);
+  long t = (long)(p * 65536.0 + 0.5);
+  d.thr = p <= 0.f ? 0u : (unsigned)(t > 65535 ? 65535 : t);
+  d.inv_keep = d.thr ? 65536.0f / (float)(65536u - d.thr) : 1.0f;
+  return d;
+}
+
 // Bijective XCD-aware remap of a 1-D block id: blocks b and b+8 share an XCD
 // (round-robin dispatch), so give every XCD one contiguous chunk of the tile list
 // and neighbouring tiles (which share operand panels) hit the same L2.

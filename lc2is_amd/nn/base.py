@@ -64,6 +64,63 @@ def join_wgrad_stream(device) -> None:
         torch.cuda.current_stream(device).wait_stream(_wgrad_streams[device])
 
 
+class DropoutRng:
+    """Seeds for the counter-based dropout kernels (csrc/common.h).  Every dropout SITE of every forward draws one 64-bit
+    seed; the site's backward re-uses it, so no mask is ever stored.  The stream is a splitmix64 sequence started from
+    ``torch.initial_seed()`` (so ``torch.manual_seed`` makes training runs repeatable) and the process' rank."""
+
+    _state = None
+    last = {}          # site name -> (seed, p) of the most recent forward, for tests that re-create the masks
+
+    @classmethod
+    def manual_seed(cls, seed: int) -> None:
+        cls._state = seed & 0xFFFFFFFFFFFFFFFF
+
+    @classmethod
+    def next_seed(cls, site: str | None = None, p: float = 0.0) -> int:
+        if cls._state is None:
+            rank = torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
+            cls._state = (torch.initial_seed() * 0x9E3779B97F4A7C15 + rank * 0xD1B54A32D192ED03 + 0x2545F4914F6CDD1D) & 0xFFFFFFFFFFFFFFFF
+        cls._state = (cls._state + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+        z = cls._state
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        z ^= z >> 31
+        if site is not None:
+            cls.last[site] = (z, p)
+        return z
+
+
+class DropSites:
+    """The dropout sites of ONE layer in ONE training forward: rate + the seed drawn for each site (kept with the saved
+    activations, so the backward regenerates the same decisions).  ``None`` stands for "dropout inactive" (eval / p == 0)."""
+
+    def __init__(self, p: float, prefix: str = "") -> None:
+        self.p, self.prefix, self.seeds = float(p), prefix, {}
+
+    def seed(self, site: str) -> int:
+        s = self.seeds.get(site)
+        if s is None:
+            s = self.seeds[site] = DropoutRng.next_seed(self.prefix + site, self.p)
+        return s
+
+    @staticmethod
+    def make(module_training: bool, p: float, prefix: str = ""):
+        return DropSites(p, prefix) if (module_training and p > 0.0) else None
+
+
+def drop_branch_add(ds: DropSites | None, site: str, branch32: torch.Tensor, resid32: torch.Tensor) -> torch.Tensor:
+    """resid + dropout(branch): the `x + self.dropoutN(sublayer(x))` of torch's Transformer layers (fp32 rows)."""
+    return ops.dropout_rows_f32(branch32, ds.p, ds.seed(site), resid=resid32)[0]
+
+
+def drop_branch_grad16(ds: DropSites | None, site: str, g32: torch.Tensor, g16: torch.Tensor | None) -> torch.Tensor:
+    """bf16 gradient wrt a dropped branch output from the fp32 gradient wrt `resid + dropout(branch)`."""
+    if ds is None:
+        return g16 if g16 is not None else ops.cast_bf16(g32)
+    return ops.dropout_rows_f32(g32, ds.p, ds.seeds[site], out_f32=None, out_bf16=True)[1]
+
+
 def require_cuda(t: torch.Tensor, what: str) -> None:
     if not t.is_cuda:
         raise RuntimeError(

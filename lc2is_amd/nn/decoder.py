@@ -13,8 +13,9 @@ TransformerDecoderLayer's ``bias`` argument, so self_attn / linear1-2 / norm1-3 
 only the rebuilt ``multihead_attn`` keeps them.  ``bias=False`` (default) reproduces that parameter set;
 ``bias=True`` gives the torch-1.x set.  Both kinds of checkpoint load.
 
-Supported on the HIP path: batch_first=True, relu, dropout == 0 (or eval mode), norm_first True/False,
-memory_key_padding_mask; other masks raise.
+Supported on the HIP path: batch_first=True, relu, norm_first True/False, memory_key_padding_mask (other masks raise),
+dropout in training mode at all six sites of torch's layer (attention probabilities of both attentions, dropout1-3 on the
+branch outputs, dropout between activation and linear2) through counter-based in-kernel RNG (no stored masks).
 """
 from __future__ import annotations
 
@@ -24,7 +25,8 @@ import torch
 from torch import nn
 
 from .. import ops
-from .base import HipModule, WgradBatch, grad_buf, linear_bwd_params, require_cuda, vec_grad
+from .base import (DropSites, HipModule, WgradBatch, drop_branch_add, drop_branch_grad16, grad_buf, linear_bwd_params,
+                   require_cuda, vec_grad)
 
 
 class _SelfAttnParams(nn.Module):
@@ -92,9 +94,10 @@ def _layer_shadows(layer: DecoderLayer, device):
     return s, e
 
 
-def _layer_fwd(x, mem16, layer: DecoderLayer, s, B, Sq, Sk, kbias, save):
+def _layer_fwd(x, mem16, layer: DecoderLayer, s, B, Sq, Sk, kbias, save, ds: DropSites | None = None):
     """One decoder layer on the fp32 residual stream x [B*Sq, C]; mem16 bf16 [B*Sk, Ckv].
-    torch:nn/modules/transformer.py:1131-1145 (norm_first) / :1147-1156 (post-norm)."""
+    torch:nn/modules/transformer.py:1131-1145 (norm_first) / :1147-1156 (post-norm); `ds` = this forward's dropout sites
+    (_sa_block / _mha_block / _ff_block, :1158-1199)."""
     C, H = layer.d_model, layer.nhead
     D = C // H
     scale = D ** -0.5
@@ -116,8 +119,14 @@ def _layer_fwd(x, mem16, layer: DecoderLayer, s, B, Sq, Sk, kbias, save):
     else:
         h1 = ops.cast_bf16(x)
     qkv, _, _ = ops.gemm_nt(h1, s["w_in"], sa.in_proj_bias)
-    o1, lse1 = ops.attention_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, H, Sq, Sq, D, scale, save_lse=save)
-    _, x1, _ = ops.gemm_nt(o1, s["w_so"], sa.out_proj.bias, resid=x, out_bf16=None, out_f32=True)
+    pd = ds.p if ds is not None else 0.0
+    o1, lse1 = ops.attention_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, H, Sq, Sq, D, scale, save_lse=save,
+                                 dropout_p=pd, seed=ds.seed("sa_p") if ds else 0)
+    if ds is None:
+        _, x1, _ = ops.gemm_nt(o1, s["w_so"], sa.out_proj.bias, resid=x, out_bf16=None, out_f32=True)
+    else:
+        _, br, _ = ops.gemm_nt(o1, s["w_so"], sa.out_proj.bias, out_bf16=None, out_f32=True)
+        x1 = drop_branch_add(ds, "d1", br, x)
     if not nf:
         h2, x1 = ln(1, x1, True)
     # --- cross attention block
@@ -125,19 +134,29 @@ def _layer_fwd(x, mem16, layer: DecoderLayer, s, B, Sq, Sk, kbias, save):
         h2, _ = ln(2, x1, False)
     q, _, _ = ops.gemm_nt(h2, s["w_q"], bq)
     kv, _, _ = ops.gemm_nt(mem16, s["w_kv"], bkv)
-    o2, lse2 = ops.attention_fwd(q, kv[:, :C], kv[:, C:], B, H, Sq, Sk, D, scale, kbias=kbias, save_lse=save)
-    _, x2, _ = ops.gemm_nt(o2, s["w_co"], ca.out_proj.bias, resid=x1, out_bf16=None, out_f32=True)
+    o2, lse2 = ops.attention_fwd(q, kv[:, :C], kv[:, C:], B, H, Sq, Sk, D, scale, kbias=kbias, save_lse=save,
+                                 dropout_p=pd, seed=ds.seed("ca_p") if ds else 0)
+    if ds is None:
+        _, x2, _ = ops.gemm_nt(o2, s["w_co"], ca.out_proj.bias, resid=x1, out_bf16=None, out_f32=True)
+    else:
+        _, br, _ = ops.gemm_nt(o2, s["w_co"], ca.out_proj.bias, out_bf16=None, out_f32=True)
+        x2 = drop_branch_add(ds, "d2", br, x1)
     if not nf:
         h3, x2 = ln(2, x2, True)
     # --- feed forward block
     if nf:
         h3, _ = ln(3, x2, False)
     a, _, _ = ops.gemm_nt(h3, s["w1"], layer.linear1.bias, act=ops.ACT_RELU)
-    _, x3, _ = ops.gemm_nt(a, s["w2"], layer.linear2.bias, resid=x2, out_bf16=None, out_f32=True)
+    if ds is None:
+        _, x3, _ = ops.gemm_nt(a, s["w2"], layer.linear2.bias, resid=x2, out_bf16=None, out_f32=True)
+    else:
+        ops.dropout_rows_bf16(a, ds.p, ds.seed("ff"))          # in place: `a` is now dropout(relu(.)), what linear2 consumes
+        _, br, _ = ops.gemm_nt(a, s["w2"], layer.linear2.bias, out_bf16=None, out_f32=True)
+        x3 = drop_branch_add(ds, "d3", br, x2)
     if not nf:
         _, x3 = ln(3, x3, True)
     if save:
-        sv.update(h1=h1, qkv=qkv, o1=o1, lse1=lse1, h2=h2, q=q, kv=kv, o2=o2, lse2=lse2, h3=h3, a=a)
+        sv.update(h1=h1, qkv=qkv, o1=o1, lse1=lse1, h2=h2, q=q, kv=kv, o2=o2, lse2=lse2, h3=h3, a=a, ds=ds)
     return x3, (sv if save else None)
 
 
@@ -165,11 +184,16 @@ def _layer_bwd_impl(g32, g16, dmem32, mem16, layer: DecoderLayer, s, sv, B, Sq, 
                                            need_param_grads=dg is not None)
         return a32, a16
 
-    # --- feed forward block:  x3 = x2 + W2 relu(W1 h3)      (post-norm: x3 = LN3(...))
+    ds = sv.get("ds")
+    pd = ds.p if ds is not None else 0.0
+    # --- feed forward block:  x3 = x2 + drop3(W2 drop(relu(W1 h3)))      (post-norm: x3 = LN3(...))
     if not nf:
         g32, g16 = ln_bwd(3, g32, None)
-    linear_bwd_params(g16, sv["a"], layer.linear2.weight, layer.linear2.bias)
-    dz, _, _ = ops.gemm_nt(g16, s["w2T"], None, act=ops.ACT_DRELU, aux_in=sv["a"])
+    gb16 = drop_branch_grad16(ds, "d3", g32, g16)
+    linear_bwd_params(gb16, sv["a"], layer.linear2.weight, layer.linear2.bias)
+    dz, _, _ = ops.gemm_nt(gb16, s["w2T"], None, act=ops.ACT_DRELU, aux_in=sv["a"])
+    if ds is not None:   # sv["a"] is the DROPPED activation, so DRELU already zeroed the dropped units: only 1/(1-p) is left
+        ops.dropout_rows_bf16(dz, ds.p, ds.seeds["ff"])
     linear_bwd_params(dz, sv["h3"], layer.linear1.weight, layer.linear1.bias)
     if nf:
         dh3, _, _ = ops.gemm_nt(dz, s["w1T"], None)
@@ -177,14 +201,15 @@ def _layer_bwd_impl(g32, g16, dmem32, mem16, layer: DecoderLayer, s, sv, B, Sq, 
     else:
         _, g32, _ = ops.gemm_nt(dz, s["w1T"], None, resid=g32, out_bf16=None, out_f32=True)
         g32, g16 = ln_bwd(2, g32, None)
-    # --- cross attention block: x2 = x1 + Wo attn(Wq h2, Wk mem, Wv mem)
-    linear_bwd_params(g16, sv["o2"], ca.out_proj.weight, ca.out_proj.bias)
-    do2, _, _ = ops.gemm_nt(g16, s["w_coT"], None)
+    # --- cross attention block: x2 = x1 + drop2(Wo attn(Wq h2, Wk mem, Wv mem))
+    gb16 = drop_branch_grad16(ds, "d2", g32, g16)
+    linear_bwd_params(gb16, sv["o2"], ca.out_proj.weight, ca.out_proj.bias)
+    do2, _, _ = ops.gemm_nt(gb16, s["w_coT"], None)
     q, kv = sv["q"], sv["kv"]
     dq = torch.empty_like(q)
     dkv = torch.empty_like(kv)
     ops.attention_bwd(q, kv[:, :C], kv[:, C:], sv["o2"], do2, sv["lse2"], B, H, Sq, Sk, D, scale, kbias=kbias, dq=dq,
-                      dk=dkv[:, :C], dv=dkv[:, C:])
+                      dk=dkv[:, :C], dv=dkv[:, C:], dropout_p=pd, seed=ds.seeds["ca_p"] if ds else 0)
     # packed in_proj_bias [3C] = (q, k, v): write the three slices
     gb, accb = vec_grad(ca.in_proj_bias)
     if ca.q_proj_weight.requires_grad:
@@ -204,13 +229,15 @@ def _layer_bwd_impl(g32, g16, dmem32, mem16, layer: DecoderLayer, s, sv, B, Sq, 
     else:
         _, g32, _ = ops.gemm_nt(dq, s["w_qT"], None, resid=g32, out_bf16=None, out_f32=True)
         g32, g16 = ln_bwd(1, g32, None)
-    # --- self attention block: x1 = x + Wo attn(Win h1)
-    linear_bwd_params(g16, sv["o1"], sa.out_proj.weight, sa.out_proj.bias)
-    do1, _, _ = ops.gemm_nt(g16, s["w_soT"], None)
+    # --- self attention block: x1 = x + drop1(Wo attn(Win h1))
+    gb16 = drop_branch_grad16(ds, "d1", g32, g16)
+    linear_bwd_params(gb16, sv["o1"], sa.out_proj.weight, sa.out_proj.bias)
+    do1, _, _ = ops.gemm_nt(gb16, s["w_soT"], None)
     qkv = sv["qkv"]
     dqkv = torch.empty_like(qkv)
     ops.attention_bwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], sv["o1"], do1, sv["lse1"], B, H, Sq, Sq, D, scale,
-                      dq=dqkv[:, :C], dk=dqkv[:, C:2 * C], dv=dqkv[:, 2 * C:])
+                      dq=dqkv[:, :C], dk=dqkv[:, C:2 * C], dv=dqkv[:, 2 * C:], dropout_p=pd,
+                      seed=ds.seeds["sa_p"] if ds else 0)
     linear_bwd_params(dqkv, sv["h1"], sa.in_proj_weight, sa.in_proj_bias)
     if nf:
         dh1, _, _ = ops.gemm_nt(dqkv, s["w_inT"], None)
@@ -257,8 +284,6 @@ class DecoderBlock(HipModule):
         l0 = self.layers[0]
         if not l0.batch_first:
             raise NotImplementedError("lc2is_amd DecoderBlock: only batch_first=True is implemented (the reference's use)")
-        if self.training and l0.dropout_p > 0:
-            raise NotImplementedError("lc2is_amd DecoderBlock: dropout > 0 in training mode is not implemented")
         sh = self._ensure_ready()
         B, Sq, C = tgt.shape
         Sk, Ckv = memory.shape[1], memory.shape[2]
@@ -269,8 +294,9 @@ class DecoderBlock(HipModule):
             kbias = torch.zeros(B, Sk, dtype=torch.float32, device=tgt.device)
             kbias.masked_fill_(kpm, float("-inf"))
         saved = []
-        for layer, s in zip(self.layers, sh["layers"]):
-            x, sv = _layer_fwd(x, mem16, layer, s, B, Sq, Sk, kbias, save)
+        for li, (layer, s) in enumerate(zip(self.layers, sh["layers"])):
+            ds = DropSites.make(self.training, layer.dropout_p, f"layers.{li}.")
+            x, sv = _layer_fwd(x, mem16, layer, s, B, Sq, Sk, kbias, save, ds)
             saved.append(sv)
         fin = None
         if self.norm is not None:
@@ -310,8 +336,7 @@ class DecoderBlock(HipModule):
 
 
 class PromptLayer(DecoderLayer):
-    """model/decoder.py:24-28: the same layer class with the reference's default dropout of 0.1 (so it only runs on
-    the HIP path in eval mode or when constructed with dropout=0)."""
+    """model/decoder.py:24-28: the same layer class with the reference's default dropout of 0.1."""
 
     def __init__(self, d_model: int, d_kv: int, nhead: int, dim_feedforward: int = 2048, dropout: float = 0.1,
                  activation=torch.nn.functional.relu, layer_norm_eps: float = 0.00001, batch_first: bool = False,

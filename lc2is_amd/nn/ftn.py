@@ -25,7 +25,8 @@ import torch
 from torch import nn
 
 from .. import ops
-from .base import HipModule, WgradBatch, grad_buf, linear_bwd_params, require_cuda, vec_grad
+from .base import (DropSites, HipModule, WgradBatch, drop_branch_add, drop_branch_grad16, grad_buf, linear_bwd_params,
+                   require_cuda, vec_grad)
 from .hier import _PackedAttnParams, _packed_param_grads, _split_bias
 
 
@@ -66,7 +67,7 @@ def _layer_shadow_entries(layer: _StdLayerParams, s: dict, tag: str, device):
     return [(src[n], s[tag + n], s[tag + n + "T"]) for n in names]
 
 
-def _std_layer_fwd(x32, x16, mem16, layer: _StdLayerParams, s, tag, B, P, K, save):
+def _std_layer_fwd(x32, x16, mem16, layer: _StdLayerParams, s, tag, B, P, K, save, ds=None):
     """Post-norm decoder layer (torch:nn/modules/transformer.py TransformerDecoderLayer.forward, norm_first=False)."""
     C, H = layer.d_model, layer.nhead
     D = C // H
@@ -79,20 +80,36 @@ def _std_layer_fwd(x32, x16, mem16, layer: _StdLayerParams, s, tag, B, P, K, sav
         return yb, yf, (t, m, r)
 
     qkv, _, _ = ops.gemm_nt(x16, s[tag + "w_in"], sa.in_proj_bias)
-    o1, lse1 = ops.attention_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, H, P, P, D, scale, save_lse=save)
-    _, s1, _ = ops.gemm_nt(o1, s[tag + "w_so"], sa.out_proj.bias, resid=x32, out_bf16=None, out_f32=True)
+    pd = ds.p if ds is not None else 0.0      # ds: this forward's dropout sites (torch's default 0.1 at model/ftn.py:135)
+    o1, lse1 = ops.attention_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, H, P, P, D, scale, save_lse=save,
+                                 dropout_p=pd, seed=ds.seed("sa_p") if ds else 0)
+    if ds is None:
+        _, s1, _ = ops.gemm_nt(o1, s[tag + "w_so"], sa.out_proj.bias, resid=x32, out_bf16=None, out_f32=True)
+    else:
+        _, br, _ = ops.gemm_nt(o1, s[tag + "w_so"], sa.out_proj.bias, out_bf16=None, out_f32=True)
+        s1 = drop_branch_add(ds, "d1", br, x32)
     h2, x1, sv["ln1"] = ln(layer.norm1, s1)
     cq, ckv = _split_bias(ca.in_proj_bias, C)
     q2, _, _ = ops.gemm_nt(h2, s[tag + "w_cin"][:C], cq)
     kv2, _, _ = ops.gemm_nt(mem16, s[tag + "w_cin"][C:], ckv)
-    o2, lse2 = ops.attention_fwd(q2, kv2[:, :C], kv2[:, C:], B, H, P, K, D, scale, save_lse=save)
-    _, s2, _ = ops.gemm_nt(o2, s[tag + "w_co"], ca.out_proj.bias, resid=x1, out_bf16=None, out_f32=True)
+    o2, lse2 = ops.attention_fwd(q2, kv2[:, :C], kv2[:, C:], B, H, P, K, D, scale, save_lse=save, dropout_p=pd,
+                                 seed=ds.seed("ca_p") if ds else 0)
+    if ds is None:
+        _, s2, _ = ops.gemm_nt(o2, s[tag + "w_co"], ca.out_proj.bias, resid=x1, out_bf16=None, out_f32=True)
+    else:
+        _, br, _ = ops.gemm_nt(o2, s[tag + "w_co"], ca.out_proj.bias, out_bf16=None, out_f32=True)
+        s2 = drop_branch_add(ds, "d2", br, x1)
     h3, x2, sv["ln2"] = ln(layer.norm2, s2)
     a, _, _ = ops.gemm_nt(h3, s[tag + "w1"], layer.linear1.bias, act=ops.ACT_RELU)
-    _, s3, _ = ops.gemm_nt(a, s[tag + "w2"], layer.linear2.bias, resid=x2, out_bf16=None, out_f32=True)
+    if ds is None:
+        _, s3, _ = ops.gemm_nt(a, s[tag + "w2"], layer.linear2.bias, resid=x2, out_bf16=None, out_f32=True)
+    else:
+        ops.dropout_rows_bf16(a, ds.p, ds.seed("ff"))          # in place: what linear2 consumes
+        _, br, _ = ops.gemm_nt(a, s[tag + "w2"], layer.linear2.bias, out_bf16=None, out_f32=True)
+        s3 = drop_branch_add(ds, "d3", br, x2)
     y16, y32, sv["ln3"] = ln(layer.norm3, s3)
     if save:
-        sv.update(x16=x16, qkv=qkv, o1=o1, lse1=lse1, h2=h2, q2=q2, kv2=kv2, o2=o2, lse2=lse2, h3=h3, a=a)
+        sv.update(ds=ds, x16=x16, qkv=qkv, o1=o1, lse1=lse1, h2=h2, q2=q2, kv2=kv2, o2=o2, lse2=lse2, h3=h3, a=a)
     return y32, y16, (sv if save else None)
 
 
@@ -117,28 +134,36 @@ def _std_layer_bwd_impl(g32, dmem32, mem16, layer: _StdLayerParams, s, tag, sv, 
                                            need_param_grads=dg is not None)
         return a32, a16
 
+    ds = sv.get("ds")
+    pd = ds.p if ds is not None else 0.0
     d32, d16 = ln_bwd(layer.norm3, g32, sv["ln3"])
+    d16 = drop_branch_grad16(ds, "d3", d32, d16)
     linear_bwd_params(d16, sv["a"], layer.linear2.weight, layer.linear2.bias)
     dz, _, _ = ops.gemm_nt(d16, s[tag + "w2T"], None, act=ops.ACT_DRELU, aux_in=sv["a"])
+    if ds is not None:   # sv["a"] is the dropped activation: DRELU zeroed the dropped units, 1/(1-p) is left to apply
+        ops.dropout_rows_bf16(dz, ds.p, ds.seeds["ff"])
     linear_bwd_params(dz, sv["h3"], layer.linear1.weight, layer.linear1.bias)
     _, d32, _ = ops.gemm_nt(dz, s[tag + "w1T"], None, resid=d32, out_bf16=None, out_f32=True)
     d32, d16 = ln_bwd(layer.norm2, d32, sv["ln2"])
+    d16 = drop_branch_grad16(ds, "d2", d32, d16)
     linear_bwd_params(d16, sv["o2"], ca.out_proj.weight, ca.out_proj.bias)
     do2, _, _ = ops.gemm_nt(d16, s[tag + "w_coT"], None)
     q2, kv2 = sv["q2"], sv["kv2"]
     dq2, dkv2 = torch.empty_like(q2), torch.empty_like(kv2)
     ops.attention_bwd(q2, kv2[:, :C], kv2[:, C:], sv["o2"], do2, sv["lse2"], B, H, P, K, D, scale, dq=dq2,
-                      dk=dkv2[:, :C], dv=dkv2[:, C:])
+                      dk=dkv2[:, :C], dv=dkv2[:, C:], dropout_p=pd, seed=ds.seeds["ca_p"] if ds else 0)
     _packed_param_grads(ca, dq2, sv["h2"], dkv2, mem16, C)
     ops.gemm_nt(dkv2, s[tag + "w_cinT"][:, C:], None, resid=dmem32, out_bf16=None, out_f32=dmem32)
     _, d32, _ = ops.gemm_nt(dq2, s[tag + "w_cinT"][:, :C], None, resid=d32, out_bf16=None, out_f32=True)
     d32, d16 = ln_bwd(layer.norm1, d32, sv["ln1"])
+    d16 = drop_branch_grad16(ds, "d1", d32, d16)
     linear_bwd_params(d16, sv["o1"], sa.out_proj.weight, sa.out_proj.bias)
     do1, _, _ = ops.gemm_nt(d16, s[tag + "w_soT"], None)
     qkv = sv["qkv"]
     dqkv = torch.empty_like(qkv)
     ops.attention_bwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], sv["o1"], do1, sv["lse1"], B, H, P, P, D, scale,
-                      dq=dqkv[:, :C], dk=dqkv[:, C:2 * C], dv=dqkv[:, 2 * C:])
+                      dq=dqkv[:, :C], dk=dqkv[:, C:2 * C], dv=dqkv[:, 2 * C:], dropout_p=pd,
+                      seed=ds.seeds["sa_p"] if ds else 0)
     linear_bwd_params(dqkv, sv["x16"], sa.in_proj_weight, sa.in_proj_bias)
     _, dx32, _ = ops.gemm_nt(dqkv, s[tag + "w_inT"], None, resid=d32, out_bf16=None, out_f32=True)
     return dx32
@@ -197,9 +222,6 @@ class Transformer(HipModule):
         D = self.dim // self.nhead
         if D not in (64, 96, 128):
             raise NotImplementedError(f"lc2is_amd ftn.Transformer: head_dim {D} has no HIP attention kernel (64/96/128)")
-        if self.training and self.dropout_p > 0:
-            raise NotImplementedError("lc2is_amd ftn.Transformer: dropout > 0 in training mode is not implemented "
-                                      "(construct with dropout=0 or call .eval())")
         if self.dim != 512 and self.sr_ratio == 2:
             raise ValueError("lc2is_amd ftn.Transformer: `norm` is LayerNorm(512) in the reference, so dim must be 512")
         if P % h or (self.sr_ratio == 2 and (h % 2 or P != h * h)):
@@ -222,7 +244,8 @@ class Transformer(HipModule):
             mem16, K = x16, P
         cur = P
         for r in range(self.repeat):
-            x32, x16, svl = _std_layer_fwd(x32, x16, mem16, self._layer(r), s, f"l{r}.", B, cur, K, save)
+            ds = DropSites.make(self.training, self.dropout_p, f"trans.{r}.")
+            x32, x16, svl = _std_layer_fwd(x32, x16, mem16, self._layer(r), s, f"l{r}.", B, cur, K, save, ds)
             sv["layers"].append((svl, cur))
             if self.upsample:   # the grid height stays h (model/ftn.py:151-156)
                 x32, x16 = ops.bilinear_up_fwd(x32, B, h, cur // h, 2, want_bf16=True)

@@ -14,7 +14,8 @@ Parameter names are the reference's (``attention_stage_4.{i}.layers.{d}.self_att
 ``DecoderLayer``, ``bias=False`` (default) reproduces the parameter set the reference gets under torch 2.10 (the
 positional ``device=None`` lands on ``bias``: attention / linear / norm1-3 bias-free; ``sr`` and ``norm`` keep theirs).
 
-HIP path: sr_ratio 2, batch_first, relu, dropout 0 (or eval); head_dim in {64, 96, 128}.
+HIP path: sr_ratio 2, batch_first, relu, head_dim in {64, 96, 128}; dropout in training mode through in-kernel
+counter-based RNG (all sites of torch's layers, no stored masks).
 The stride-2 conv is a row gather + MFMA GEMM; the x2 upsamples are channels-last single-pass kernels; the whole
 pyramid runs under ONE autograd node.
 """
@@ -24,7 +25,8 @@ import torch
 from torch import nn
 
 from .. import ops
-from .base import HipModule, WgradBatch, grad_buf, linear_bwd_params, require_cuda, vec_grad
+from .base import (DropSites, HipModule, WgradBatch, drop_branch_add, drop_branch_grad16, grad_buf, linear_bwd_params,
+                   require_cuda, vec_grad)
 
 
 def _isqrt(p: int) -> int:
@@ -118,7 +120,7 @@ def _split_bias(b, C):
     return (None, None) if b is None else (b[:C], b[C:])
 
 
-def _sr_layer_fwd(x32, x16, mem16, layer: _SRLayer, s, B, P, K, save):
+def _sr_layer_fwd(x32, x16, mem16, layer: _SRLayer, s, B, P, K, save, ds=None):
     """x32/x16: fp32 stream and its bf16 twin [B*P, C]; mem16 [B*K, C] or None.  Returns (y32, y16, saved)."""
     C, H = layer.d_model, layer.nhead
     D = C // H
@@ -137,26 +139,42 @@ def _sr_layer_fwd(x32, x16, mem16, layer: _SRLayer, s, B, P, K, save):
     _, r32, _ = ops.gemm_nt(g, s["w_sr"], layer.sr.bias, out_bf16=None, out_f32=True)
     rn16, _, mr, rr = ops.layernorm_fwd(r32, layer.norm.weight, layer.norm.bias, layer.norm.eps, save_stats=save)
     kv, _, _ = ops.gemm_nt(rn16, s["w_in"][C:], bkv)
-    o1, lse1 = ops.attention_fwd(q, kv[:, :C], kv[:, C:], B, H, P, P // 4, D, scale, save_lse=save)
-    _, s1, _ = ops.gemm_nt(o1, s["w_so"], sa.out_proj.bias, resid=x32, out_bf16=None, out_f32=True)
+    pd = ds.p if ds is not None else 0.0      # training-mode dropout sites (torch Transformer layers: attention probabilities,
+    o1, lse1 = ops.attention_fwd(q, kv[:, :C], kv[:, C:], B, H, P, P // 4, D, scale, save_lse=save, dropout_p=pd,   # dropout1-3,
+                                 seed=ds.seed("sa_p") if ds else 0)                                               # feed-forward)
+    if ds is None:
+        _, s1, _ = ops.gemm_nt(o1, s["w_so"], sa.out_proj.bias, resid=x32, out_bf16=None, out_f32=True)
+    else:
+        _, br, _ = ops.gemm_nt(o1, s["w_so"], sa.out_proj.bias, out_bf16=None, out_f32=True)
+        s1 = drop_branch_add(ds, "d1", br, x32)
     h2, x1, sv["ln1"] = ln(layer.norm1, s1)
     if layer.cross:
         ca = layer.multihead_attn
         cq, ckv = _split_bias(ca.in_proj_bias, C)
         q2, _, _ = ops.gemm_nt(h2, s["w_cin"][:C], cq)
         kv2, _, _ = ops.gemm_nt(mem16, s["w_cin"][C:], ckv)
-        o2, lse2 = ops.attention_fwd(q2, kv2[:, :C], kv2[:, C:], B, H, P, K, D, scale, save_lse=save)
-        _, s2, _ = ops.gemm_nt(o2, s["w_co"], ca.out_proj.bias, resid=x1, out_bf16=None, out_f32=True)
+        o2, lse2 = ops.attention_fwd(q2, kv2[:, :C], kv2[:, C:], B, H, P, K, D, scale, save_lse=save, dropout_p=pd,
+                                     seed=ds.seed("ca_p") if ds else 0)
+        if ds is None:
+            _, s2, _ = ops.gemm_nt(o2, s["w_co"], ca.out_proj.bias, resid=x1, out_bf16=None, out_f32=True)
+        else:
+            _, br, _ = ops.gemm_nt(o2, s["w_co"], ca.out_proj.bias, out_bf16=None, out_f32=True)
+            s2 = drop_branch_add(ds, "d2", br, x1)
         h3, x2, sv["ln2"] = ln(layer.norm2, s2)
         last = layer.norm3
     else:
         h3, x2 = h2, x1
         last = layer.norm2
     a, _, _ = ops.gemm_nt(h3, s["w1"], layer.linear1.bias, act=ops.ACT_RELU)
-    _, s3, _ = ops.gemm_nt(a, s["w2"], layer.linear2.bias, resid=x2, out_bf16=None, out_f32=True)
+    if ds is None:
+        _, s3, _ = ops.gemm_nt(a, s["w2"], layer.linear2.bias, resid=x2, out_bf16=None, out_f32=True)
+    else:
+        ops.dropout_rows_bf16(a, ds.p, ds.seed("ff"))          # in place: what linear2 consumes
+        _, br, _ = ops.gemm_nt(a, s["w2"], layer.linear2.bias, out_bf16=None, out_f32=True)
+        s3 = drop_branch_add(ds, "d3", br, x2)
     y16, y32, sv["ln3"] = ln(last, s3)
     if save:
-        sv.update(x16=x16, q=q, g=g, r32=r32, mr=mr, rr=rr, rn16=rn16, kv=kv, o1=o1, lse1=lse1, h2=h2, h3=h3, a=a)
+        sv.update(ds=ds, x16=x16, q=q, g=g, r32=r32, mr=mr, rr=rr, rn16=rn16, kv=kv, o1=o1, lse1=lse1, h2=h2, h3=h3, a=a)
         if layer.cross:
             sv.update(q2=q2, kv2=kv2, o2=o2, lse2=lse2)
     return y32, y16, (sv if save else None)
@@ -198,31 +216,38 @@ def _sr_layer_bwd_impl(g32, dmem32, mem16, layer: _SRLayer, s, sv, B, P, K):
                                            need_param_grads=dg is not None)
         return a32, a16
 
+    ds = sv.get("ds")
+    pd = ds.p if ds is not None else 0.0
     last = layer.norm3 if layer.cross else layer.norm2
-    d32, d16 = ln_bwd(last, g32, sv["ln3"])                                # wrt s3 = x2 + W2 relu(W1 h3)
+    d32, d16 = ln_bwd(last, g32, sv["ln3"])                                # wrt s3 = x2 + drop3(W2 drop(relu(W1 h3)))
+    d16 = drop_branch_grad16(ds, "d3", d32, d16)
     linear_bwd_params(d16, sv["a"], layer.linear2.weight, layer.linear2.bias)
     dz, _, _ = ops.gemm_nt(d16, s["w2T"], None, act=ops.ACT_DRELU, aux_in=sv["a"])
+    if ds is not None:   # sv["a"] is the dropped activation: DRELU zeroed the dropped units, 1/(1-p) is left to apply
+        ops.dropout_rows_bf16(dz, ds.p, ds.seeds["ff"])
     linear_bwd_params(dz, sv["h3"], layer.linear1.weight, layer.linear1.bias)
     _, d32, _ = ops.gemm_nt(dz, s["w1T"], None, resid=d32, out_bf16=None, out_f32=True)      # wrt x2
     if layer.cross:
         ca = layer.multihead_attn
-        d32, d16 = ln_bwd(layer.norm2, d32, sv["ln2"])                     # wrt s2 = x1 + Wo attn(...)
+        d32, d16 = ln_bwd(layer.norm2, d32, sv["ln2"])                     # wrt s2 = x1 + drop2(Wo attn(...))
+        d16 = drop_branch_grad16(ds, "d2", d32, d16)
         linear_bwd_params(d16, sv["o2"], ca.out_proj.weight, ca.out_proj.bias)
         do2, _, _ = ops.gemm_nt(d16, s["w_coT"], None)
         q2, kv2 = sv["q2"], sv["kv2"]
         dq2, dkv2 = torch.empty_like(q2), torch.empty_like(kv2)
         ops.attention_bwd(q2, kv2[:, :C], kv2[:, C:], sv["o2"], do2, sv["lse2"], B, H, P, K, D, scale, dq=dq2,
-                          dk=dkv2[:, :C], dv=dkv2[:, C:])
+                          dk=dkv2[:, :C], dv=dkv2[:, C:], dropout_p=pd, seed=ds.seeds["ca_p"] if ds else 0)
         _packed_param_grads(ca, dq2, sv["h2"], dkv2, mem16, C)
         ops.gemm_nt(dkv2, s["w_cinT"][:, C:], None, resid=dmem32, out_bf16=None, out_f32=dmem32)
         _, d32, _ = ops.gemm_nt(dq2, s["w_cinT"][:, :C], None, resid=d32, out_bf16=None, out_f32=True)   # wrt x1
-    d32, d16 = ln_bwd(layer.norm1, d32, sv["ln1"])                         # wrt s1 = x + Wo attn(q(x), kv(sr(x)))
+    d32, d16 = ln_bwd(layer.norm1, d32, sv["ln1"])                         # wrt s1 = x + drop1(Wo attn(q(x), kv(sr(x))))
+    d16 = drop_branch_grad16(ds, "d1", d32, d16)
     linear_bwd_params(d16, sv["o1"], sa.out_proj.weight, sa.out_proj.bias)
     do1, _, _ = ops.gemm_nt(d16, s["w_soT"], None)
     q, kv = sv["q"], sv["kv"]
     dq, dkv = torch.empty_like(q), torch.empty_like(kv)
     ops.attention_bwd(q, kv[:, :C], kv[:, C:], sv["o1"], do1, sv["lse1"], B, H, P, P // 4, D, scale, dq=dq, dk=dkv[:, :C],
-                      dv=dkv[:, C:])
+                      dv=dkv[:, C:], dropout_p=pd, seed=ds.seeds["sa_p"] if ds else 0)
     _packed_param_grads(sa, dq, sv["x16"], dkv, sv["rn16"], C)
     drn16, _, _ = ops.gemm_nt(dkv, s["w_inT"][:, C:], None)
     dg, accg = vec_grad(layer.norm.weight)
@@ -280,12 +305,11 @@ class _SRBlock(HipModule):
         layer = self._l
         if not layer.batch_first:
             raise NotImplementedError("lc2is_amd SR blocks: only batch_first=True is implemented")
-        if self.training and layer.dropout_p > 0:
-            raise NotImplementedError("lc2is_amd SR blocks: dropout > 0 in training mode is not implemented")
         s = self._ensure_ready()
         saved = []
-        for _ in range(self.depth):
-            x32, x16, sv = _sr_layer_fwd(x32, x16, mem16, layer, s, B, P, K, save)
+        for it in range(self.depth):     # the SAME layer `depth` times (shared weights), fresh dropout decisions each time
+            ds = DropSites.make(self.training, layer.dropout_p, f"sr{it}.")
+            x32, x16, sv = _sr_layer_fwd(x32, x16, mem16, layer, s, B, P, K, save, ds)
             saved.append(sv)
         hw = _isqrt(P)
         y32, y16 = ops.bilinear_up_fwd(x32, B, hw, hw, self.upsample, want_bf16=True)

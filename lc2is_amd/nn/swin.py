@@ -14,8 +14,9 @@ HIP design: tokens as rows of an fp32 residual stream; per block  LN -> index-ma
 window partition in one pass) -> fused QKV MFMA GEMM -> window attention kernel (relative-position bias + region mask
 in-kernel) -> output GEMM -> index-map gather back fused with the residual add -> LN -> fc1+GELU(erf) -> fc2+residual.
 Channel counts that are not multiples of 64 (Swin-small/tiny stage 1: 96, 3x96) are zero-padded in the bf16 operand
-buffers and weight shadows.  Dropout / drop-path must be 0 (the reference's config default drop_path_rate is 0.1:
-pass ``drop_path_rate=0`` or call ``.eval()``); the whole backbone is ONE autograd node.
+buffers and weight shadows.  Drop-path (the config default drop_path_rate = 0.1, SwinDropPath on the attention branch) runs in
+training mode from per-sample counter-based decisions (no stored mask); hidden / attention dropout are 0 in the config
+(hf SwinConfig defaults) and are not modelled.  The whole backbone is ONE autograd node.
 """
 from __future__ import annotations
 
@@ -37,7 +38,7 @@ class SwinArch:
     patch: int = 4
     eps: float = 1e-5
     mlp_ratio: int = 4
-    drop_path_rate: float = 0.1       # hf SwinConfig default; only 0 (or eval mode) runs on the HIP path
+    drop_path_rate: float = 0.1       # hf SwinConfig default
 
 
 SWIN_T = SwinArch(96, (2, 2, 6, 2), (3, 6, 12, 24))
@@ -340,7 +341,7 @@ class SwinTransformer(HipModule):
             gb.add_(b) if accb else gb.copy_(b)
 
     # ---- one block ------------------------------------------------------------------------------------------------------
-    def _block_fwd(self, x32, blk: _Block, s, ctx, shift, save):
+    def _block_fwd(self, x32, blk: _Block, s, ctx, shift, save, dp=None):
         a = self.arch
         B, H, W, C, nH = ctx["B"], ctx["H"], ctx["W"], ctx["C"], ctx["nH"]
         Cp, ws = _r64(C), a.window
@@ -355,14 +356,16 @@ class SwinTransformer(HipModule):
         _, lse = ops.swin_attn_fwd(qkv[:, :3 * C], s["bias"], mp["nwin"], mp["per_img"], mp["nwx"], mp["Hp"], mp["Wp"], ws,
                                    shift, nH, 32 ** -0.5, save_lse=save, out=o16p[:, :C])
         _, y32, _ = ops.gemm_nt(o16p, s["wo"], blk.attention.o_proj.bias, out_bf16=None, out_f32=True)   # [Mw, C]
-        x_mid = ops.rows_gather(y32, mp["inv"], add=x32)                                          # un-window + residual
+        if dp is not None:   # SwinDropPath on the attention branch (modeling_swin.py:567): one decision per SAMPLE; in window
+            ops.dropout_rows_f32(y32, dp[0], dp[1], out_f32=y32, rows_per_sample=mp["per_img"] * ws * ws)   # order a sample
+        x_mid = ops.rows_gather(y32, mp["inv"], add=x32)          # owns per_img windows.  un-window + residual
         h2 = self._padded(M, C, Cp, x32.device)
         _, _, m2, r2 = ops.layernorm_fwd(x_mid, blk.layernorm_after.weight, blk.layernorm_after.bias, a.eps, save_stats=save,
                                          out_bf16=h2[:, :C])
         act, _, z = ops.gemm_nt(h2, s["w1"], blk.mlp.fc1.bias, act=ops.ACT_GELU_ERF, aux_out=True if save else None)
         _, x_out, _ = ops.gemm_nt(act, s["w2"], blk.mlp.fc2.bias, resid=x_mid, out_bf16=None, out_f32=True)
         sv = dict(x=x32, m1=m1, r1=r1, win16=win16, qkv=qkv, o16p=o16p, lse=lse, x_mid=x_mid, m2=m2, r2=r2, h2=h2, z=z,
-                  act=act, shift=shift) if save else None
+                  act=act, shift=shift, dp=dp) if save else None
         return x_out, sv
 
     def _block_bwd(self, g32, blk: _Block, s, ctx, sv):
@@ -388,7 +391,10 @@ class SwinTransformer(HipModule):
         # x_mid = x + unwindow(o_proj(attn(qkv(window(LN_before(x))))))
         Mw = mp["fwd"].numel()
         dy16 = self._padded(Mw, C, Cp, g32.device)
-        ops.rows_gather(gm32, mp["fwd"], out=dy16, cols=C)                                        # pad rows -> 0
+        gbr32 = gm32
+        if sv["dp"] is not None:   # gradient wrt the drop-path'ed attention branch: the forward's per-sample decisions again
+            gbr32, _ = ops.dropout_rows_f32(gm32, sv["dp"][0], sv["dp"][1], rows_per_sample=H * W)
+        ops.rows_gather(gbr32, mp["fwd"], out=dy16, cols=C)                                       # pad rows -> 0
         self._wgrad_padded(dy16[:, :C], sv["o16p"], at.o_proj.weight, at.o_proj.bias, C)
         do16, _, _ = ops.gemm_nt(dy16, s["woT"], None)                                            # [Mw, C]
         S = ws * ws
@@ -436,9 +442,6 @@ class SwinTransformer(HipModule):
     def _fwd(self, pixel_values, save):
         require_cuda(pixel_values, "pixel_values")
         a = self.arch
-        if self.training and a.drop_path_rate > 0:
-            raise NotImplementedError("lc2is_amd SwinTransformer: drop_path_rate > 0 in training mode is not implemented "
-                                      "(construct with drop_path_rate=0 or call .eval())")
         B, ch, Hi, Wi = pixel_values.shape
         if ch != 3 or Hi != Wi or Hi % a.patch:
             raise ValueError("lc2is_amd SwinTransformer: expects square [B,3,H,W] images with H divisible by the patch size")
@@ -459,7 +462,10 @@ class SwinTransformer(HipModule):
             ctx = dict(B=B, H=H, W=W, C=C, nH=a.num_heads[si])
             svb = []
             for bi, (blk, s) in enumerate(zip(st.blocks, ss["blocks"])):
-                x, sv = self._block_fwd(x, blk, s, ctx, 0 if bi % 2 == 0 else a.window // 2, save)
+                # stochastic depth: rate rises linearly over ALL blocks of the four stages (modeling_swin.py:758)
+                rate = a.drop_path_rate * (sum(a.depths[:si]) + bi) / max(sum(a.depths) - 1, 1)
+                dp = (rate, DropoutRng.next_seed(f"swin.{si}.{bi}.drop_path", rate)) if (self.training and rate > 0) else None
+                x, sv = self._block_fwd(x, blk, s, ctx, 0 if bi % 2 == 0 else a.window // 2, save, dp)
                 svb.append(sv)
             x, svm = self._merge_fwd(x, st.downsample, ss, ctx, save)
             H, W = (H + 1) // 2, (W + 1) // 2

@@ -17,7 +17,7 @@ from . import _lib
 ACT_NONE, ACT_QUICK_GELU, ACT_RELU, ACT_DQUICK_GELU, ACT_DRELU, ACT_QUICK_GELU_GRAD, ACT_MUL_AUX = 0, 1, 2, 3, 4, 5, 6
 ACT_GELU_ERF, ACT_DGELU_ERF = 7, 8
 
-_P, _I, _F, _Z, _L = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_long
+_P, _I, _F, _Z, _L, _U64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_long, C.c_ulonglong
 _ARGTYPES = {
     "lc2is_gemm_nt_bf16": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "lc2is_gemm_nt_bf16_batched": [_P, _I, _L, _P, _I, _L, _P, _I, _L, _P, _I, _L, _I, _I, _I, _I, _P],
@@ -33,6 +33,12 @@ _ARGTYPES = {
     "lc2is_attention_fwd": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "lc2is_attention_bwd": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P,
                             _I, _I, _I, _I, _I, _F, _I, _P],
+    "lc2is_attention_fwd_dropout": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _I, _F, _U64, _P],
+    "lc2is_attention_bwd_dropout": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P,
+                                    _I, _I, _I, _I, _I, _F, _I, _F, _U64, _P],
+    "lc2is_dropout_rows_f32": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _F, _U64, _P],
+    "lc2is_dropout_rows_bf16": [_P, _I, _P, _I, _I, _I, _F, _U64, _P],
+    "lc2is_dropout_mask": [_P, _L, _I, _F, _U64, _P],
     "lc2is_shadow_refresh": [_P, _I, _I, _P],
     "lc2is_cast_f32_bf16": [_P, _I, _P, _I, _I, _I, _P],
     "lc2is_transpose_bf16": [_P, _I, _P, _I, _I, _I, _P],
@@ -320,8 +326,9 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: 
 
 def attention_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, H: int, Sq: int, Sk: int, D: int,
                   scale: float, *, causal: bool = False, kbias: torch.Tensor | None = None,
-                  save_lse: bool = True, out: torch.Tensor | None = None):
-    """q [B*Sq, H*D], k/v [B*Sk, H*D] bf16 2-D views (any row stride).  Returns (o [B*Sq, H*D] bf16, lse2)."""
+                  save_lse: bool = True, out: torch.Tensor | None = None, dropout_p: float = 0.0, seed: int = 0):
+    """q [B*Sq, H*D], k/v [B*Sk, H*D] bf16 2-D views (any row stride).  Returns (o [B*Sq, H*D] bf16, lse2).
+    dropout_p > 0: dropout on the attention probabilities, decisions = f(seed, (b,h,q), key) (pass the same to attention_bwd)."""
     _chk(q, torch.bfloat16, "q"); _chk(k, torch.bfloat16, "k"); _chk(v, torch.bfloat16, "v")
     _chk(kbias, torch.float32, "kbias")
     if q.shape != (B * Sq, H * D) or k.shape != (B * Sk, H * D) or v.shape != (B * Sk, H * D):
@@ -331,15 +338,21 @@ def attention_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, H: 
     o = out if out is not None else torch.empty((B * Sq, H * D), dtype=torch.bfloat16, device=q.device)
     _chk(o, torch.bfloat16, "out")
     lse = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device) if save_lse else None
-    rc = _fn("lc2is_attention_fwd")(_ptr(q), _ld(q), _ptr(k), _ld(k), _ptr(v), _ld(v), _ptr(o), _ld(o),
-                                    _ptr(lse), _ptr(kbias), B, H, Sq, Sk, D, float(scale), int(causal),
-                                    _stream())
+    if dropout_p > 0.0:
+        rc = _fn("lc2is_attention_fwd_dropout")(_ptr(q), _ld(q), _ptr(k), _ld(k), _ptr(v), _ld(v), _ptr(o), _ld(o),
+                                                _ptr(lse), _ptr(kbias), B, H, Sq, Sk, D, float(scale), int(causal),
+                                                float(dropout_p), int(seed), _stream())
+    else:
+        rc = _fn("lc2is_attention_fwd")(_ptr(q), _ld(q), _ptr(k), _ld(k), _ptr(v), _ld(v), _ptr(o), _ld(o),
+                                        _ptr(lse), _ptr(kbias), B, H, Sq, Sk, D, float(scale), int(causal),
+                                        _stream())
     _lib.check(rc, f"attention_fwd B={B} H={H} Sq={Sq} Sk={Sk} D={D}")
     return o, lse
 
 
 def attention_bwd(q, k, v, o, do, lse2, B: int, H: int, Sq: int, Sk: int, D: int, scale: float, *,
-                  causal: bool = False, kbias: torch.Tensor | None = None, dq=None, dk=None, dv=None):
+                  causal: bool = False, kbias: torch.Tensor | None = None, dq=None, dk=None, dv=None,
+                  dropout_p: float = 0.0, seed: int = 0):
     """Returns (dq, dk, dv) bf16; dq/dk/dv may be preallocated 2-D views (e.g. slices of a packed dQKV)."""
     for t, n in ((q, "q"), (k, "k"), (v, "v"), (o, "o"), (do, "do")):
         _chk(t, torch.bfloat16, n)
@@ -351,12 +364,50 @@ def attention_bwd(q, k, v, o, do, lse2, B: int, H: int, Sq: int, Sk: int, D: int
     for t, n in ((dq, "dq"), (dk, "dk"), (dv, "dv")):
         _chk(t, torch.bfloat16, n)
     delta = torch.empty((B, H, Sq), dtype=torch.float32, device=dev)
-    rc = _fn("lc2is_attention_bwd")(_ptr(q), _ld(q), _ptr(k), _ld(k), _ptr(v), _ld(v), _ptr(o), _ld(o),
-                                    _ptr(do), _ld(do), _ptr(dq), _ld(dq), _ptr(dk), _ld(dk), _ptr(dv), _ld(dv),
-                                    _ptr(lse2), _ptr(delta), _ptr(kbias), B, H, Sq, Sk, D, float(scale),
-                                    int(causal), _stream())
+    args = (_ptr(q), _ld(q), _ptr(k), _ld(k), _ptr(v), _ld(v), _ptr(o), _ld(o), _ptr(do), _ld(do), _ptr(dq), _ld(dq),
+            _ptr(dk), _ld(dk), _ptr(dv), _ld(dv), _ptr(lse2), _ptr(delta), _ptr(kbias), B, H, Sq, Sk, D, float(scale),
+            int(causal))
+    if dropout_p > 0.0:
+        rc = _fn("lc2is_attention_bwd_dropout")(*args, float(dropout_p), int(seed), _stream())
+    else:
+        rc = _fn("lc2is_attention_bwd")(*args, _stream())
     _lib.check(rc, f"attention_bwd B={B} H={H} Sq={Sq} Sk={Sk} D={D}")
     return dq, dk, dv
+
+
+def dropout_rows_f32(x: torch.Tensor, p: float, seed: int, *, resid: torch.Tensor | None = None,
+                     out_f32: torch.Tensor | bool | None = True, out_bf16: torch.Tensor | bool | None = None,
+                     rows_per_sample: int = 0):
+    """y = resid + keep * x / (1 - p) on fp32 rows [M,C]; one decision per element, or per sample of `rows_per_sample` rows
+    (drop-path).  Returns (y_f32 or None, y_bf16 or None).  Applied to a gradient with the forward's (p, seed) it is the
+    backward of the same site."""
+    _chk(x, torch.float32, "x"); _chk(resid, torch.float32, "resid")
+    M, Cc = x.shape
+    yf = _out(out_f32, (M, Cc), torch.float32, x.device)
+    yb = _out(out_bf16, (M, Cc), torch.bfloat16, x.device)
+    _chk(yf, torch.float32, "out_f32"); _chk(yb, torch.bfloat16, "out_bf16")
+    rc = _fn("lc2is_dropout_rows_f32")(_ptr(x), _ld(x), _ptr(resid), _ld(resid), _ptr(yf), _ld(yf), _ptr(yb), _ld(yb), M, Cc,
+                                       int(rows_per_sample), float(p), int(seed), _stream())
+    _lib.check(rc, f"dropout_rows_f32 M={M} C={Cc}")
+    return yf, yb
+
+
+def dropout_rows_bf16(x: torch.Tensor, p: float, seed: int, out: torch.Tensor | None = None):
+    """bf16 [M,C] -> keep * x / (1 - p), in place unless `out` is given."""
+    _chk(x, torch.bfloat16, "x")
+    y = x if out is None else out
+    _chk(y, torch.bfloat16, "out")
+    M, Cc = x.shape
+    rc = _fn("lc2is_dropout_rows_bf16")(_ptr(x), _ld(x), _ptr(y), _ld(y), M, Cc, float(p), int(seed), _stream())
+    _lib.check(rc, f"dropout_rows_bf16 M={M} C={Cc}")
+    return y
+
+
+def dropout_mask(rows: int, cols: int, p: float, seed: int, device) -> torch.Tensor:
+    """The decisions keep(seed, r, c) as a uint8 [rows, cols] tensor — for tests (the product path never stores a mask)."""
+    out = torch.empty((rows, cols), dtype=torch.uint8, device=device)
+    _lib.check(_fn("lc2is_dropout_mask")(_ptr(out), rows, cols, float(p), int(seed), _stream()), "dropout_mask")
+    return out
 
 
 INTERP_BICUBIC, INTERP_BILINEAR = 0, 1

@@ -46,10 +46,12 @@ def quick_gelu(x: Tensor) -> Tensor:
     return x * torch.sigmoid(1.702 * x)
 
 
-def mha_core(q: Tensor, k: Tensor, v: Tensor, nhead: int, scale: float, bias: Tensor | None) -> Tensor:
+def mha_core(q: Tensor, k: Tensor, v: Tensor, nhead: int, scale: float, bias: Tensor | None,
+             pdrop: Tensor | None = None) -> Tensor:
     """softmax(scale * Q K^T + bias) V per head.  q [B,Sq,C], k/v [B,Sk,C]; bias broadcastable to [B,H,Sq,Sk].
     Follows hf:modeling_clip.py:259-277 (eager_attention_forward) and the attention core of
-    torch:nn/functional.py multi_head_attention_forward."""
+    torch:nn/functional.py multi_head_attention_forward.  pdrop [B,H,Sq,Sk] (optional): the dropout multiplier
+    keep / (1 - p) applied to the attention probabilities (training mode, F.dropout after the softmax)."""
     B, Sq, C = q.shape
     Sk = k.shape[1]
     d = C // nhead
@@ -60,6 +62,8 @@ def mha_core(q: Tensor, k: Tensor, v: Tensor, nhead: int, scale: float, bias: Te
     if bias is not None:
         s = s + bias
     p = torch.softmax(s, dim=-1)
+    if pdrop is not None:
+        p = p * pdrop
     return (p @ vh).transpose(1, 2).reshape(B, Sq, C)
 
 
@@ -220,11 +224,15 @@ def text_encoder_clip_pooler(sd, pre, input_ids, attention_mask, cfg) -> Tensor:
 # decoder (model/decoder.py:9-21 -> torch TransformerDecoderLayer / MultiheadAttention)
 # ----------------------------------------------------------------------------------------------------------
 def decoder_layer(sd: dict, pre: str, tgt: Tensor, memory: Tensor, nhead: int, norm_first: bool = True,
-                  memory_key_padding_mask: Tensor | None = None, eps: float = 1e-5) -> Tensor:
+                  memory_key_padding_mask: Tensor | None = None, eps: float = 1e-5, drop: dict | None = None) -> Tensor:
     """DecoderLayer.forward = torch:nn/modules/transformer.py:1131-1145 with multihead_attn rebuilt for
     kdim=vdim=d_kv (separate q/k/v projection weights, packed in_proj_bias).  Biases are optional: under
-    torch 2.10 the reference creates self_attn / linear1-2 / norm1-3 without them (SURVEY.md §2 drift #1)."""
+    torch 2.10 the reference creates self_attn / linear1-2 / norm1-3 without them (SURVEY.md §2 drift #1).
+    drop (training mode, :1158-1199): multipliers keep / (1 - p) for the six dropout sites — "sa_p", "ca_p"
+    [B,H,Sq,Sk] on the attention probabilities, "d1", "d2", "d3" [B,Sq,C] on the branch outputs, "ff" [B,Sq,F] between
+    the activation and linear2; a missing key means no dropout at that site."""
     g = lambda k: sd.get(pre + k)  # noqa: E731
+    dm = (lambda name, t: t * drop[name] if (drop is not None and name in drop) else t)  # noqa: E731
     C = tgt.shape[-1]
     scale = (C // nhead) ** -0.5
 
@@ -232,8 +240,8 @@ def decoder_layer(sd: dict, pre: str, tgt: Tensor, memory: Tensor, nhead: int, n
         w, b = g("self_attn.in_proj_weight"), g("self_attn.in_proj_bias")
         qkv = linear(x, w, b)
         q, k, v = qkv.split(C, dim=-1)
-        a = mha_core(q, k, v, nhead, scale, None)
-        return linear(a, g("self_attn.out_proj.weight"), g("self_attn.out_proj.bias"))
+        a = mha_core(q, k, v, nhead, scale, None, drop.get("sa_p") if drop else None)
+        return dm("d1", linear(a, g("self_attn.out_proj.weight"), g("self_attn.out_proj.bias")))
 
     def ca(x):
         b = g("multihead_attn.in_proj_bias")
@@ -245,12 +253,12 @@ def decoder_layer(sd: dict, pre: str, tgt: Tensor, memory: Tensor, nhead: int, n
         if memory_key_padding_mask is not None:
             bias = torch.zeros(memory.shape[0], 1, 1, memory.shape[1], dtype=x.dtype)
             bias = bias.masked_fill(memory_key_padding_mask[:, None, None, :], float("-inf"))
-        a = mha_core(q, k, v, nhead, scale, bias)
-        return linear(a, g("multihead_attn.out_proj.weight"), g("multihead_attn.out_proj.bias"))
+        a = mha_core(q, k, v, nhead, scale, bias, drop.get("ca_p") if drop else None)
+        return dm("d2", linear(a, g("multihead_attn.out_proj.weight"), g("multihead_attn.out_proj.bias")))
 
     def ff(x):
-        return linear(torch.relu(linear(x, g("linear1.weight"), g("linear1.bias"))), g("linear2.weight"),
-                      g("linear2.bias"))
+        return dm("d3", linear(dm("ff", torch.relu(linear(x, g("linear1.weight"), g("linear1.bias")))), g("linear2.weight"),
+                               g("linear2.bias")))
 
     n = lambda i, x: layer_norm(x, g(f"norm{i}.weight"), g(f"norm{i}.bias"), eps)  # noqa: E731
     x = tgt
@@ -265,11 +273,12 @@ def decoder_layer(sd: dict, pre: str, tgt: Tensor, memory: Tensor, nhead: int, n
     return x
 
 
-def decoder_block(sd, pre, tgt, memory, nhead, num_layers, norm_first=True, memory_key_padding_mask=None):
-    """DecoderBlock.forward (model/decoder.py:20-21): num_layers layers, no final norm."""
+def decoder_block(sd, pre, tgt, memory, nhead, num_layers, norm_first=True, memory_key_padding_mask=None, drops=None):
+    """DecoderBlock.forward (model/decoder.py:20-21): num_layers layers, no final norm.  drops: per-layer dropout multipliers."""
     x = tgt
     for i in range(num_layers):
-        x = decoder_layer(sd, f"{pre}layers.{i}.", x, memory, nhead, norm_first, memory_key_padding_mask)
+        x = decoder_layer(sd, f"{pre}layers.{i}.", x, memory, nhead, norm_first, memory_key_padding_mask,
+                          drop=drops[i] if drops else None)
     return x
 
 
@@ -411,7 +420,8 @@ def evaluate(sd: dict, batches: list, cfg: BaseCfg) -> dict:
 # ----------------------------------------------------------------------------------------------------------
 # multi-scale decoders (BASELINE config 5): model/hierarchical.py, model/decoder.py:36-134
 # ----------------------------------------------------------------------------------------------------------
-def _mha_packed(sd: dict, pre: str, q_in: Tensor, kv_in: Tensor, nhead: int, bias: Tensor | None = None) -> Tensor:
+def _mha_packed(sd: dict, pre: str, q_in: Tensor, kv_in: Tensor, nhead: int, bias: Tensor | None = None,
+                pdrop: Tensor | None = None) -> Tensor:
     """nn.MultiheadAttention with a packed in_proj_weight [3C,C] (q from q_in, k/v from kv_in), optional biases
     (absent under the torch-2.10 `bias` drift)."""
     C = q_in.shape[-1]
@@ -421,7 +431,7 @@ def _mha_packed(sd: dict, pre: str, q_in: Tensor, kv_in: Tensor, nhead: int, bia
     q = linear(q_in, w[:C], bq)
     k = linear(kv_in, w[C:2 * C], bk)
     v = linear(kv_in, w[2 * C:], bv)
-    a = mha_core(q, k, v, nhead, (C // nhead) ** -0.5, bias)
+    a = mha_core(q, k, v, nhead, (C // nhead) ** -0.5, bias, pdrop)
     return linear(a, sd[pre + "out_proj.weight"], sd.get(pre + "out_proj.bias"))
 
 
@@ -435,27 +445,36 @@ def sr_reduce(sd: dict, pre: str, x: Tensor) -> Tensor:
     return layer_norm(r, sd[pre + "norm.weight"], sd[pre + "norm.bias"], 1e-5)
 
 
-def sr_cross_layer(sd: dict, pre: str, tgt: Tensor, memory: Tensor, nhead: int, eps: float = 1e-5) -> Tensor:
+def _dm(drop, name, t):
+    """Apply the dropout multiplier keep / (1 - p) of site `name` when one is given (training mode)."""
+    return t * drop[name] if (drop is not None and name in drop) else t
+
+
+def sr_cross_layer(sd: dict, pre: str, tgt: Tensor, memory: Tensor, nhead: int, eps: float = 1e-5, drop: dict | None = None) -> Tensor:
     """SRTransformerCrossA / SRTransformerDecoder forward (post-norm TransformerDecoderLayer whose self-attention
     keys/values are the spatially reduced tokens): model/hierarchical.py:201-225, model/decoder.py:113-134,
     torch:nn/modules/transformer.py:1147-1156."""
     g = lambda k: sd.get(pre + k)  # noqa: E731
+    pd = (lambda k: drop.get(k) if drop else None)  # noqa: E731
     x = tgt
-    x = layer_norm(x + _mha_packed(sd, pre + "self_attn.", x, sr_reduce(sd, pre, x), nhead), g("norm1.weight"),
-                   g("norm1.bias"), eps)
-    x = layer_norm(x + _mha_packed(sd, pre + "multihead_attn.", x, memory, nhead), g("norm2.weight"), g("norm2.bias"), eps)
-    ff = linear(torch.relu(linear(x, g("linear1.weight"), g("linear1.bias"))), g("linear2.weight"), g("linear2.bias"))
-    return layer_norm(x + ff, g("norm3.weight"), g("norm3.bias"), eps)
+    x = layer_norm(x + _dm(drop, "d1", _mha_packed(sd, pre + "self_attn.", x, sr_reduce(sd, pre, x), nhead, None, pd("sa_p"))),
+                   g("norm1.weight"), g("norm1.bias"), eps)
+    x = layer_norm(x + _dm(drop, "d2", _mha_packed(sd, pre + "multihead_attn.", x, memory, nhead, None, pd("ca_p"))),
+                   g("norm2.weight"), g("norm2.bias"), eps)
+    ff = linear(_dm(drop, "ff", torch.relu(linear(x, g("linear1.weight"), g("linear1.bias")))), g("linear2.weight"),
+                g("linear2.bias"))
+    return layer_norm(x + _dm(drop, "d3", ff), g("norm3.weight"), g("norm3.bias"), eps)
 
 
-def sr_self_layer(sd: dict, pre: str, src: Tensor, nhead: int, eps: float = 1e-5) -> Tensor:
+def sr_self_layer(sd: dict, pre: str, src: Tensor, nhead: int, eps: float = 1e-5, drop: dict | None = None) -> Tensor:
     """SRTransformerSelfA forward (post-norm TransformerEncoderLayer), model/hierarchical.py:174-199."""
     g = lambda k: sd.get(pre + k)  # noqa: E731
     x = src
-    x = layer_norm(x + _mha_packed(sd, pre + "self_attn.", x, sr_reduce(sd, pre, x), nhead), g("norm1.weight"),
-                   g("norm1.bias"), eps)
-    ff = linear(torch.relu(linear(x, g("linear1.weight"), g("linear1.bias"))), g("linear2.weight"), g("linear2.bias"))
-    return layer_norm(x + ff, g("norm2.weight"), g("norm2.bias"), eps)
+    x = layer_norm(x + _dm(drop, "d1", _mha_packed(sd, pre + "self_attn.", x, sr_reduce(sd, pre, x), nhead, None,
+                                                   drop.get("sa_p") if drop else None)), g("norm1.weight"), g("norm1.bias"), eps)
+    ff = linear(_dm(drop, "ff", torch.relu(linear(x, g("linear1.weight"), g("linear1.bias")))), g("linear2.weight"),
+                g("linear2.bias"))
+    return layer_norm(x + _dm(drop, "d3", ff), g("norm2.weight"), g("norm2.bias"), eps)
 
 
 def _up2_tokens(x: Tensor, factor: int = 2) -> Tensor:
@@ -465,12 +484,14 @@ def _up2_tokens(x: Tensor, factor: int = 2) -> Tensor:
     return y.permute(0, 2, 3, 1).reshape(B, P * factor * factor, C)
 
 
-def attn_block(sd: dict, pre: str, x: Tensor, memory: Tensor | None, nhead: int, depth: int, layer_key: str) -> Tensor:
+def attn_block(sd: dict, pre: str, x: Tensor, memory: Tensor | None, nhead: int, depth: int, layer_key: str,
+               drops: list | None = None) -> Tensor:
     """CrossABlock / SelfABlock / FTNBlock: `depth` applications of ONE shared layer, then bilinear x2
-    (model/hierarchical.py:140-172, model/decoder.py:103-111)."""
-    for _ in range(depth):
-        x = sr_cross_layer(sd, pre + layer_key, x, memory, nhead) if memory is not None else \
-            sr_self_layer(sd, pre + layer_key, x, nhead)
+    (model/hierarchical.py:140-172, model/decoder.py:103-111).  drops: per-application dropout multipliers."""
+    for it in range(depth):
+        d = drops[it] if drops else None
+        x = sr_cross_layer(sd, pre + layer_key, x, memory, nhead, drop=d) if memory is not None else \
+            sr_self_layer(sd, pre + layer_key, x, nhead, drop=d)
     return _up2_tokens(x)
 
 
@@ -495,15 +516,20 @@ def hierarchical(sd: dict, pre: str, visual: list, textual: Tensor | None, nhead
 # ----------------------------------------------------------------------------------------------------------
 # the older FTN pyramid: model/ftn.py:67-157
 # ----------------------------------------------------------------------------------------------------------
-def std_decoder_layer(sd: dict, pre: str, tgt: Tensor, memory: Tensor, nhead: int, eps: float = 1e-5) -> Tensor:
+def std_decoder_layer(sd: dict, pre: str, tgt: Tensor, memory: Tensor, nhead: int, eps: float = 1e-5,
+                      drop: dict | None = None) -> Tensor:
     """nn.TransformerDecoderLayer(d, nhead, batch_first=True) forward, post-norm, relu, dropout off
     (torch:nn/modules/transformer.py:1147-1156), as instantiated at model/ftn.py:135."""
     g = lambda k: sd.get(pre + k)  # noqa: E731
+    pd = (lambda k: drop.get(k) if drop else None)  # noqa: E731
     x = tgt
-    x = layer_norm(x + _mha_packed(sd, pre + "self_attn.", x, x, nhead), g("norm1.weight"), g("norm1.bias"), eps)
-    x = layer_norm(x + _mha_packed(sd, pre + "multihead_attn.", x, memory, nhead), g("norm2.weight"), g("norm2.bias"), eps)
-    ff = linear(torch.relu(linear(x, g("linear1.weight"), g("linear1.bias"))), g("linear2.weight"), g("linear2.bias"))
-    return layer_norm(x + ff, g("norm3.weight"), g("norm3.bias"), eps)
+    x = layer_norm(x + _dm(drop, "d1", _mha_packed(sd, pre + "self_attn.", x, x, nhead, None, pd("sa_p"))), g("norm1.weight"),
+                   g("norm1.bias"), eps)
+    x = layer_norm(x + _dm(drop, "d2", _mha_packed(sd, pre + "multihead_attn.", x, memory, nhead, None, pd("ca_p"))),
+                   g("norm2.weight"), g("norm2.bias"), eps)
+    ff = linear(_dm(drop, "ff", torch.relu(linear(x, g("linear1.weight"), g("linear1.bias")))), g("linear2.weight"),
+                g("linear2.bias"))
+    return layer_norm(x + _dm(drop, "d3", ff), g("norm3.weight"), g("norm3.bias"), eps)
 
 
 def _up2_grid(x: Tensor, h: int) -> Tensor:
@@ -514,12 +540,12 @@ def _up2_grid(x: Tensor, h: int) -> Tensor:
 
 
 def ftn_transformer(sd: dict, pre: str, x: Tensor, h: int, repeat: int, sr_ratio: int, upsample: bool,
-                    nhead: int) -> Tensor:
+                    nhead: int, drops: list | None = None) -> Tensor:
     """ftn.Transformer.forward (model/ftn.py:143-157): memory = LayerNorm(Conv2d(k=sr, s=sr)(x grid)) of the block
     input (x itself when sr_ratio == 1); `repeat` decoder layers, each followed by the x2 upsample when enabled."""
     memory = sr_reduce(sd, pre, x) if sr_ratio > 1 else x
     for r in range(repeat):
-        x = std_decoder_layer(sd, f"{pre}trans.{r}.layers.0.", x, memory, nhead)
+        x = std_decoder_layer(sd, f"{pre}trans.{r}.layers.0.", x, memory, nhead, drop=drops[r] if drops else None)
         if upsample:
             x = _up2_grid(x, h)
     return x
@@ -576,8 +602,10 @@ def swin_relative_position_index(ws: int) -> Tensor:
     return rel.sum(-1).view(-1)
 
 
-def swin_block(sd: dict, pre: str, x: Tensor, H: int, W: int, nH: int, ws: int, shift: int, eps: float) -> Tensor:
-    """SwinLayer.forward (modeling_swin.py:529-574), dropout / drop-path off."""
+def swin_block(sd: dict, pre: str, x: Tensor, H: int, W: int, nH: int, ws: int, shift: int, eps: float,
+               drop_path: Tensor | None = None) -> Tensor:
+    """SwinLayer.forward (modeling_swin.py:529-574).  drop_path [B] (training mode): SwinDropPath's per-sample multiplier
+    keep / (1 - p) on the attention branch (:567; the MLP branch only has nn.Dropout(hidden_dropout_prob = 0), :571)."""
     B, L, C = x.shape
     if min(H, W) <= ws:
         raise NotImplementedError("oracle swin_block: grids no larger than the window are outside the path (512^2 input)")
@@ -610,7 +638,10 @@ def swin_block(sd: dict, pre: str, x: Tensor, H: int, W: int, nH: int, ws: int, 
     o = o.view(B, Hp // ws, Wp // ws, ws, ws, C).transpose(2, 3).reshape(B, Hp, Wp, C)
     if shift > 0:
         o = torch.roll(o, shifts=(shift, shift), dims=(1, 2))
-    x = x + o[:, :H, :W, :].reshape(B, H * W, C)
+    o = o[:, :H, :W, :].reshape(B, H * W, C)
+    if drop_path is not None:
+        o = o * drop_path.view(B, 1, 1)
+    x = x + o
     h2 = layer_norm(x, g("layernorm_after.weight"), g("layernorm_after.bias"), eps)
     h2 = linear(h2, g("mlp.fc1.weight"), g("mlp.fc1.bias"))
     h2 = 0.5 * h2 * (1.0 + torch.erf(h2 * 0.7071067811865476))                          # hf:activations "gelu" (exact)
@@ -629,7 +660,7 @@ def swin_patch_merging(sd: dict, pre: str, x: Tensor, H: int, W: int, eps: float
     return linear(f, sd[pre + "reduction.weight"], None)
 
 
-def swin_hidden_states(sd: dict, pre: str, pixel_values: Tensor, cfg: SwinCfg, n_out: int = 4) -> list:
+def swin_hidden_states(sd: dict, pre: str, pixel_values: Tensor, cfg: SwinCfg, n_out: int = 4, drop_paths: dict | None = None) -> list:
     """SwinTransformer.forward (model/encoder.py:129-131): SwinModel(..., output_hidden_states=True).hidden_states[:4]
     = (patch embedding output, stage 1/2/3 outputs AFTER their patch merging); `pre` is the reference's attribute path
     ("encoder.").  Stage 4 and the final layernorm never reach those four tensors and are not evaluated."""
@@ -646,7 +677,8 @@ def swin_hidden_states(sd: dict, pre: str, pixel_values: Tensor, cfg: SwinCfg, n
     for si in range(n_out - 1):
         for bi in range(cfg.depths[si]):
             x = swin_block(sd, f"{pre}encoder.layers.{si}.blocks.{bi}.", x, H, W, cfg.num_heads[si], cfg.window,
-                           0 if bi % 2 == 0 else cfg.window // 2, cfg.eps)
+                           0 if bi % 2 == 0 else cfg.window // 2, cfg.eps,
+                           drop_paths.get((si, bi)) if drop_paths else None)   # {(stage, block): [B] multipliers}
         x = swin_patch_merging(sd, f"{pre}encoder.layers.{si}.downsample.", x, H, W, cfg.eps)
         H, W = (H + 1) // 2, (W + 1) // 2
         outs.append(x)

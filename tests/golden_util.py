@@ -59,3 +59,28 @@ def config1_batch(i: int, in_size: int = 128, out_size: int = 32, L: int = 16):
     mask = torch.zeros(1, L, dtype=torch.int64)
     mask[0, :12] = 1
     return dict(pixel_values=pix, input_ids=ids, attention_mask=mask, label=lab), None
+
+
+DROP_SITES = ("sa_p", "d1", "ca_p", "d2", "ff", "d3")     # call order of F.dropout inside torch's TransformerDecoderLayer
+
+
+def dropout_case(seed: int, norm_first: bool, B=2, K=24, P=40, d_model=128, d_kv=192, nhead=2, F=256, layers=2, p=0.25):
+    """Inputs + per-layer dropout multipliers keep/(1-p) for the six sites of a decoder layer (tiny dims)."""
+    g = torch.Generator().manual_seed(seed)
+    tgt = torch.randn(B, K, d_model, generator=g)
+    mem = torch.randn(B, P, d_kv, generator=g)
+    dout = torch.randn(B, K, d_model, generator=g) * 0.1
+    shapes = dict(sa_p=(B, nhead, K, K), d1=(B, K, d_model), ca_p=(B, nhead, K, P), d2=(B, K, d_model), ff=(B, K, F),
+                  d3=(B, K, d_model))
+    drops = [{s: (torch.rand(shapes[s], generator=g) >= p).float() / (1.0 - p) for s in DROP_SITES} for _ in range(layers)]
+    return tgt, mem, dout, drops
+
+
+def swin_droppath_inputs(seed: int = 63, B: int = 4):
+    """Inputs of the drop-path fixture (tools/make_golden.py make_swin_droppath): pixels, per-block keep decisions [8, B]
+    (call order of the SwinDropPath modules) and the output gradients of the four hidden states of the tiny Swin."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, 3, 176, 176, generator=g)
+    keeps = (torch.rand(8, B, generator=g) >= 0.4).float()
+    douts = [torch.randn(B, n, c, generator=g) * 0.2 for n, c in ((1936, 32), (484, 64), (121, 128), (36, 256))]
+    return x, keeps, douts

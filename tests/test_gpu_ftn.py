@@ -59,10 +59,11 @@ def test_ftn_decoder_vs_reference(dev):
             assert float(g.abs().mean()) < 1e-3, k
             continue
         assert abs(float(g.abs().sum()) - ref_abs) < 0.1 * ref_abs, (k, float(g.abs().sum()), ref_abs)
-    # training mode with the reference's hard-coded dropout must fail loudly, not silently skip the dropout
+    # training mode with the reference's hard-coded dropout 0.1 (model/ftn.py:135) runs and IS stochastic
     m.train()
-    with pytest.raises(NotImplementedError):
-        m([x.detach() for x in xs])
+    with torch.no_grad():
+        o1, o2 = m([x.detach() for x in xs]), m([x.detach() for x in xs])
+    assert torch.isfinite(o1).all() and _rel(o1, o2) > 1e-3 and _rel(o1[:, ::st], fx["out"]) > 1e-2
 
 
 @pytest.mark.parametrize("sr_ratio,repeat,upsample", [(2, 2, True), (1, 1, False)])

@@ -393,6 +393,52 @@ def make_swin(R):
     print("swin:", [tuple(o.shape) for o in outs], "params without grad:", len(fx["no_grad"]), "full grads:", len(keep))
 
 
+def make_swin_droppath(R):
+    """The same tiny SwinModel as make_swin in TRAINING mode with drop_path_rate = 0.2 and KNOWN per-sample decisions:
+    SwinDropPath.forward is replaced, for the reference's own forward, by a multiply with the next prepared [B] vector of
+    keep / (1 - p_block) (p_block from the module's own drop_prob).  Pins where stochastic depth acts and its rates."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    from golden_util import make_weights
+    from transformers import SwinConfig, SwinModel
+    from transformers.models.swin import modeling_swin as MS
+    cfg = SwinConfig(image_size=176, patch_size=4, embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], window_size=5,
+                     drop_path_rate=0.2)
+    cfg._attn_implementation = "eager"
+    m = _bare(R["renc"].SwinTransformer)
+    m.encoder = SwinModel(cfg)
+    m.train()
+    params = dict(m.named_parameters())
+    shapes = {k: list(v.shape) for k, v in params.items()}
+    w = make_weights(shapes, 61)
+    with torch.no_grad():
+        for k, p in params.items():
+            p.copy_(w[k])
+    from golden_util import swin_droppath_inputs
+    x, keeps, douts = swin_droppath_inputs(63, 4)              # keeps: one row per SwinDropPath call (40 % dropped)
+    rates, used = [], []
+    real = MS.SwinDropPath.forward
+
+    def fake(self, hidden_states):
+        i = len(used)
+        used.append(float(self.drop_prob))
+        return hidden_states * (keeps[i] / (1.0 - self.drop_prob)).view(-1, 1, 1)
+
+    MS.SwinDropPath.forward = fake
+    try:
+        outs = m(x)
+        assert [tuple(o.shape) for o in outs] == [tuple(d.shape) for d in douts]
+        sum((o * d).sum() for o, d in zip(outs, douts)).backward()
+    finally:
+        MS.SwinDropPath.forward = real
+    keep_g = ["encoder.encoder.layers.0.blocks.1.attention.q_proj.weight", "encoder.encoder.layers.2.blocks.1.attention.o_proj.weight",
+              "encoder.embeddings.patch_embeddings.projection.weight", "encoder.encoder.layers.1.blocks.0.mlp.fc1.weight"]
+    fx = dict(iseed=torch.tensor(63), ncalls=torch.tensor(len(used)), rates=torch.tensor(used), outs=[o.detach() for o in outs],
+              grad_full={k: params[k].grad.clone() for k in keep_g})
+    torch.save(fx, OUT / "swin_droppath.pt")
+    print("swin drop-path: calls", len(used), "rates", [round(r, 4) for r in used])
+
+
+
 def make_prompt(R):
     """PromptDecoder(PromptLayer(512, 1024, 8, batch_first=True), 2) — the reference's construction at model/model.py:183
     (post-norm, dropout 0.1 default, d_kv != d_model), here 2 layers deep — in EVAL mode (dropout inactive; identical
@@ -464,6 +510,59 @@ def make_clip_full(R):
 
 
 
+def make_dropout(R):
+    """Training-mode dropout of the reference's decoder layers (PromptLayer: post-norm, model/decoder.py:24-28; DecoderLayer
+    with norm_first=True, :9-13) with KNOWN masks: torch.nn.functional.dropout is replaced, for the duration of the
+    reference's own forward, by a function that multiplies by the next prepared keep/(1-p) tensor; the attention modules
+    are asked for need_weights=True so that torch takes its explicit softmax -> dropout -> matmul path
+    (torch:nn/functional.py multi_head_attention_forward) instead of the fused SDPA kernel, whose mask is not observable.
+    Pins WHERE the six dropouts act; the fixture stores the reference's outputs and gradients only."""
+    import torch.nn.functional as F
+    sys.path.insert(0, str(ROOT / "tests"))
+    from golden_util import DROP_SITES, dropout_case, make_weights
+    fx = {}
+    for tag, cls, nf in (("post", R["rdec"].PromptLayer, False), ("pre", R["rdec"].DecoderLayer, True)):
+        torch.manual_seed(51)
+        layer = cls(d_model=128, d_kv=192, nhead=2, dim_feedforward=256, dropout=0.25, batch_first=True, norm_first=nf)
+        dec = (R["rdec"].PromptDecoder if not nf else R["rdec"].DecoderBlock)(layer, num_layers=2)
+        named = dict(dec.named_parameters())
+        shapes = {k: list(v.shape) for k, v in named.items()}
+        w = make_weights(shapes, 52)
+        with torch.no_grad():
+            for k, p_ in named.items():
+                p_.copy_(w[k])
+        dec.train()
+        tgt, mem, dout, drops = dropout_case(53 + int(nf), nf)
+        queue = [d[s_] for d in drops for s_ in DROP_SITES]
+        for l in dec.layers:       # explicit-softmax path of torch's MHA (the dropout call is then a Python-level F.dropout)
+            for mha in (l.self_attn, l.multihead_attn):
+                orig = mha.forward
+                mha.forward = (lambda o: (lambda *a, **kw: o(*a, **{**kw, "need_weights": True})))(orig)
+        real = F.dropout
+
+        def fake(input, p=0.5, training=True, inplace=False):
+            assert training and abs(p - 0.25) < 1e-9
+            m = queue.pop(0)
+            return input * m.reshape(input.shape)
+
+        F.dropout = fake
+        try:
+            tgt.requires_grad_(True); mem.requires_grad_(True)
+            out = dec(tgt=tgt, memory=mem) if not nf else dec(tgt=tgt, memory=mem)
+            out.backward(dout)
+        finally:
+            F.dropout = real
+        assert not queue, len(queue)
+        grads = {k: p_.grad.detach().clone() for k, p_ in named.items()}
+        fx[tag] = dict(shapes={k: torch.tensor(v) for k, v in shapes.items()}, out=out.detach().clone(), dtgt=tgt.grad.clone(),
+                       dmem=mem.grad.clone(), grad_stats={k: torch.stack([v.sum(), v.abs().sum()]) for k, v in grads.items()},
+                       grad_full={k: grads[k] for k in ("layers.0.linear1.weight", "layers.1.multihead_attn.k_proj_weight",
+                                                        "layers.0.self_attn.in_proj_weight", "layers.1.norm2.weight")})
+        print("dropout", tag, "out", tuple(out.shape))
+    torch.save(fx, OUT / "decoder_dropout.pt")
+
+
+
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
     R = _ref_imports()
@@ -479,6 +578,10 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "swin":
         make_swin(R)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "dropout":
+        make_dropout(R)
+        make_swin_droppath(R)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "prompt":
         make_prompt(R)
         make_clip_full(R)
@@ -492,6 +595,8 @@ def main():
     make_contrastive(R)
     make_prompt(R)
     make_clip_full(R)
+    make_dropout(R)
+    make_swin_droppath(R)
     # the reference's only data fixture on this path — copied as-is
     protos = torch.load(REF / "model" / "ade20k_prototypes.pt", weights_only=True)
     torch.save(protos.clone(), OUT / "ade20k_prototypes.pt")
