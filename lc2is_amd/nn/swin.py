@@ -26,7 +26,7 @@ import torch
 from torch import nn
 
 from .. import ops
-from .base import HipModule, WgradBatch, grad_buf, linear_bwd_params, require_cuda, vec_grad
+from .base import DropoutRng, HipModule, WgradBatch, grad_buf, linear_bwd_params, require_cuda, vec_grad
 
 
 @dataclass(frozen=True)
