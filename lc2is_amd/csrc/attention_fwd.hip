@@ -36,14 +36,42 @@ struct AttnFwdArgs {
   DropCfg drop;         // attention-probability dropout (DROP instantiations only)
 };
 
+// K and V tiles (64 keys) live in LDS as ONE kind of image, filled by LDS-DMA (buffer_load ... lds, no staging registers, no
+// ds_write) and read BOTH by rows (ds_read_b128: the K fragments of S^T) and transposed (ds_read_b64_tr_b16: the V^T fragments
+// of O^T): rows of PITCH bytes, 16-byte chunk index XOR-swizzled by row bits so that both kinds of read are bank-conflict free
+// (the image of attention_bwd.hip; rocprofv3 SQ_LDS_BANK_CONFLICT = 0 there).  An LDS-DMA wave instruction writes 1 KiB
+// linearly, so the swizzle is applied on the per-lane SOURCE address and the reads use the same involution.
 template <int D> struct AttnCfg {
-  static constexpr int KS = D * 2 + 16;                 // K row pitch (bytes)
-  static constexpr int VS = (D <= 96) ? 192 : 320;      // V row pitch: == 64 or 192 (mod 256), >= 2D
-  static constexpr int KT = 64 * KS, VT = 64 * VS;
-  static constexpr int STAGE = KT + VT + 256;           // + 64 fp32 bias values
-  static constexpr int CH = D / 8;                      // 16-byte chunks per row
-  static constexpr int NCH = 64 * CH / 256;             // chunks per thread per operand tile
+  static constexpr int PITCH = (D == 64) ? 128 : 256;
+  static constexpr int TILE = 64 * PITCH;               // one operand tile
+  static constexpr int STAGE = 2 * TILE;                // K image | V image
+  static constexpr int NSTAGE = (D == 64) ? 3 : 2;      // ring depth: tiles are requested NSTAGE-1 ahead (3 x 16 KiB / 2 x 32 KiB)
+  static constexpr int CH = D / 8;                      // 16-byte chunks of data per row
+  static constexpr int SLOTS = PITCH / 16;              // 16-byte slots per row
+  static constexpr int RPP = 1024 / PITCH;              // rows per 1-KiB DMA piece
+  static constexpr int PPW = 64 / RPP / 4;              // pieces per wave per operand tile
+  static constexpr int IPT = 2 * PPW;                   // DMA instructions per wave per tile
+  __device__ static __forceinline__ int swz(int row) {
+    if constexpr (D == 64) return (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
+    else return ((row & 3) << 2) | ((row >> 2) & 3);
+  }
+  __device__ static __forceinline__ int off(int row, int ch) { return row * PITCH + ((ch ^ swz(row)) << 4); }
 };
+
+// (the LDS-DMA builtin lives in a helper that takes no buffer-resource parameter: see gemm_nt.hip)
+template <int D>
+__device__ __forceinline__ void attn_dma_tile(const bf16_t* K, unsigned kbytes, const bf16_t* V, unsigned vbytes, char* stage,
+                                              int wid, const int* k_goff, const int* v_goff, int kstep, int vstep) {
+  using Cfg = AttnCfg<D>;
+  const __amdgpu_buffer_rsrc_t rsK = make_rsrc(K, kbytes);
+  const __amdgpu_buffer_rsrc_t rsV = make_rsrc(V, vbytes);
+#pragma unroll
+  for (int j = 0; j < Cfg::PPW; ++j) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, LDS_PTR(stage + (wid * Cfg::PPW + j) * 1024), 16, k_goff[j], kstep, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, LDS_PTR(stage + Cfg::TILE + (wid * Cfg::PPW + j) * 1024), 16, v_goff[j], vstep,
+                                             0, 0);
+  }
+}
 
 __device__ __forceinline__ bf16x8_t tr_frag2(const char* base, int addr_lo, int addr_hi) {
   const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -54,264 +82,310 @@ __device__ __forceinline__ bf16x8_t tr_frag2(const char* base, int addr_lo, int 
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
-// DBG (diagnostic builds, LC2IS_ATTN_DBG; results are WRONG by design): bit 0 = no softmax arithmetic, bit 1 = K / V^T fragments
-// read from LDS once before the loop, bit 2 = no global loads / LDS stores inside the loop, bit 3 = no P.V MFMAs
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+  float d;   // one VALU op for two comparisons (hipcc otherwise canonicalises the MFMA outputs before every fmaxf)
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
+// Structure (S = 1025, D = 64 measured on MI355X, rocprofv3 + ablation builds of the round-1 form: 28 % of the launch was per-block
+// prologue / epilogue latency and the key loop ran at ~600 cycles per 64-key wave-tile for 512 cycles of MFMA work because
+// each wave is one serial chain  QK^T -> max -> lane exchange -> branch -> exp2 -> P.V  with 2-3 waves per SIMD to hide it):
+//  * a wave owns QW x 32 queries (QW = 2 at D = 64): two independent chains per wave, every K and V^T fragment read from LDS
+//    feeds two MFMAs, and a block (4 waves) amortises its prologue / epilogue and its K/V stream over 256 queries;
+//  * K/V tiles arrive by LDS-DMA into a ring (3 deep at D = 64) behind counted s_waitcnt vmcnt + one raw s_barrier per tile;
+//  * every row keeps its state (O, l) in a FRAME m_ref: O = sum_k exp2(s_k - m_ref) v_k.  A tile adds exp2(s - m_ref) in the
+//    same frame, so nothing is rescaled and the lane halves that share a row do not talk to each other.  Only when some row's
+//    tile maximum exceeds its frame by more than FRAME_THR (or a row meets its first unmasked key) the wave takes a rare branch:
+//    the halves exchange their maxima, the row moves to the frame of its new maximum (O, l times exp2(m_ref - m_ref')), and
+//    the S^T chain of this tile is redone in the new frame.  Probabilities are therefore <= 2^FRAME_THR and >= their true
+//    value relative to a real score: no overflow, no row-wide underflow;
+//  * a score costs one fma (scale and frame), half a max3, one exp2, one add and half a pack (tried and dropped: Q pre-multiplied
+//    by scale*log2(e) in bf16 with -m_ref fed through an extra MFMA saves the fma but rounds Q once more — 2-3e-3 on scores and
+//    log-sum-exp — and measured no faster);
+//  * O leaves through LDS as whole 2D-byte rows (row-per-lane stores touch 32 cache lines per instruction).
 // DROP: dropout on the attention probabilities (torch multi_head_attention_forward dropout_p in training mode,
-// torch:nn/functional.py:6206): the normaliser l sums the UNDROPPED probabilities, O accumulates keep * P / (1 - p);
+// torch:nn/functional.py:6206): l sums the UNDROPPED probabilities, O accumulates keep * P / (1 - p);
 // coordinate of a score = (row (b*H + h)*Sq + q, column key), so the backward kernels regenerate the same decisions.
-template <int D, int DBG = 0, bool DROP = false>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnFwdArgs p) {
+constexpr float FRAME_THR = 6.0f;
+
+template <int D, int QW, bool DROP>
+__global__ __launch_bounds__(256, (D == 64 && QW == 1) ? 3 : 2) void attn_fwd_kernel(AttnFwdArgs p) {
   using Cfg = AttnCfg<D>;
-  constexpr int KS = Cfg::KS, VS = Cfg::VS, CH = Cfg::CH, NCH = Cfg::NCH;
+  constexpr int PITCH = Cfg::PITCH, NSTAGE = Cfg::NSTAGE, PD = NSTAGE - 1;
   constexpr int NKS = D / 16, NDT = D / 32;
+  constexpr int QB = 128 * QW;          // queries per block
+  constexpr int OP = 2 * D + 16;        // row pitch of the output staging image (bytes)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hh = lane >> 5, l31 = lane & 31;
   // 1-D grid, XCD-aware: the query blocks of one (batch, head) — which stream the same K / V — are neighbours in the tile
   // order, and xcd_remap gives every XCD (its own L2) one contiguous chunk of that order
-  const int nqb = (p.Sq + 127) / 128;
+  const int nqb = (p.Sq + QB - 1) / QB;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int bx = tile % nqb, head = (tile / nqb) % p.H, b = tile / (nqb * p.H);
-  const int q0 = bx * 128 + wid * 32;
-  const int qrow = q0 + l31;
-  const bool wave_active = q0 < p.Sq;   // wave-uniform (wid comes from threadIdx.x >> 6)
+  const int q0 = bx * QB + wid * 32 * QW;            // first query of this wave
+  const bool wave_active = q0 < p.Sq;                 // wave-uniform; later sub-tiles of a ragged wave compute on zero rows
   const float NEG_INF = -__builtin_inff();
-  const unsigned drop_rh = DROP ? drop_row_hash(p.drop, (unsigned)((b * p.H + head) * p.Sq + qrow)) : 0u;
 
   int nkt = (p.Sk + 63) / 64;
   if (p.causal) {
-    const int lim = (bx * 128 + 128 + 63) / 64;  // keys <= last query of the block
+    const int lim = (bx * QB + QB + 63) / 64;  // keys <= last query of the block
     if (lim < nkt) nkt = lim;
   }
 
   const unsigned qbytes = (unsigned)p.B * p.Sq * p.ldq * 2u;
   const unsigned kbytes = (unsigned)p.B * p.Sk * p.ldk * 2u, vbytes = (unsigned)p.B * p.Sk * p.ldv * 2u;
-  const __amdgpu_buffer_rsrc_t rsQ = make_rsrc(p.Q, qbytes);
-  const __amdgpu_buffer_rsrc_t rsK = make_rsrc(p.K, kbytes);
-  const __amdgpu_buffer_rsrc_t rsV = make_rsrc(p.V, vbytes);
 
-  // Q fragments (B operand of S^T = K·Q^T): lane holds Q[qrow][16s + 8hh .. +7]
-  bf16x8_t qf[NKS];
+  // LDS-DMA bookkeeping: piece j of this wave covers rows RPP*(wid*PPW + j) .. +RPP-1 of the tile; lane l fills slot l % SLOTS
+  // of row l / SLOTS with the source chunk that the swizzle maps there (chunks past the row's data read as zero: offset -1)
+  int k_goff[Cfg::PPW], v_goff[Cfg::PPW];
+#pragma unroll
+  for (int j = 0; j < Cfg::PPW; ++j) {
+    const int row = Cfg::RPP * (wid * Cfg::PPW + j) + lane / Cfg::SLOTS;
+    const int ch = (lane % Cfg::SLOTS) ^ Cfg::swz(row);
+    k_goff[j] = ch < Cfg::CH ? ((b * p.Sk + row) * p.ldk + head * D + ch * 8) * 2 : -1;
+    v_goff[j] = ch < Cfg::CH ? ((b * p.Sk + row) * p.ldv + head * D + ch * 8) * 2 : -1;
+  }
+  auto request = [&](int kt) {   // tile kt -> ring slot kt % NSTAGE
+    attn_dma_tile<D>(p.K, kbytes, p.V, vbytes, smem + (kt % NSTAGE) * Cfg::STAGE, wid, k_goff, v_goff, kt * 64 * p.ldk * 2,
+                     kt * 64 * p.ldv * 2);
+  };
+  // the first PD tiles are on their way before anything else happens (their latency overlaps the Q loads below)
+#pragma unroll
+  for (int i = 0; i < PD; ++i)
+    if (i < nkt) request(i);
+
+  // Q fragments (B operand of S^T = K·Q^T): lane holds Q[q][16s + 8hh .. +7] of its QW queries
+  bf16x8_t qf[QW][NKS];
+  unsigned drop_rh[QW];
   {
-    const int off = (qrow < p.Sq) ? ((b * p.Sq + qrow) * p.ldq + head * D + 8 * hh) * 2 : -1;
+    const __amdgpu_buffer_rsrc_t rsQ = make_rsrc(p.Q, qbytes);
 #pragma unroll
-    for (int s = 0; s < NKS; ++s) {
-      const i32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsQ, off < 0 ? -1 : off + s * 32, 0, 0);
-      qf[s] = __builtin_bit_cast(bf16x8_t, v);
-    }
-  }
-
-  // staging bookkeeping
-  int k_goff[NCH], v_goff[NCH], k_lds[NCH], v_lds[NCH];
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int c = tid + i * 256, row = c / CH, ch = c % CH;
-    k_goff[i] = ((b * p.Sk + row) * p.ldk + head * D + ch * 8) * 2;
-    v_goff[i] = ((b * p.Sk + row) * p.ldv + head * D + ch * 8) * 2;
-    k_lds[i] = row * KS + ch * 16;
-    v_lds[i] = Cfg::KT + row * VS + ch * 16;
-  }
-  i32x4_t rk[NCH], rv[NCH];
-  float rbias = 0.f;
-  auto gload = [&](int kt) {
-    const int kb = kt * 64 * p.ldk * 2, vb = kt * 64 * p.ldv * 2;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      rk[i] = __builtin_amdgcn_raw_buffer_load_b128(rsK, k_goff[i] + kb, 0, 0);
-      rv[i] = __builtin_amdgcn_raw_buffer_load_b128(rsV, v_goff[i] + vb, 0, 0);
-    }
-    if (tid < 64) {
-      const int key = kt * 64 + tid;
-      rbias = (key < p.Sk) ? (p.kbias ? p.kbias[(size_t)b * p.Sk + key] * 1.44269504088896341f : 0.f) : NEG_INF;
-    }
-  };
-  auto lstore = [&](char* stage) {
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      *(i32x4_t*)(stage + k_lds[i]) = rk[i];
-      *(i32x4_t*)(stage + v_lds[i]) = rv[i];
-    }
-    if (tid < 64) *(float*)(stage + Cfg::KT + Cfg::VT + tid * 4) = rbias;
-  };
-
-  // fragment addresses
-  const int k_frag = l31 * KS + 16 * hh;  // + 32t*KS + 32*s
-  const int q4 = (lane >> 2) & 3, p4 = lane & 3, cg = (lane >> 4) & 1;
-  const int v_frag = (4 * hh + q4) * VS + (16 * cg + 4 * p4) * 2;  // + (32t+16s2)*VS + 64*dt ; hi = +8*VS
-
-  f32x16_t ot[NDT];
-#pragma unroll
-  for (int d = 0; d < NDT; ++d)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) ot[d][r] = 0.f;
-  float m_run = NEG_INF, l_run = 0.f;
-
-  if (nkt > 0) {
-    gload(0);
-    lstore(smem);
-  }
-  __syncthreads();
-
-  for (int kt = 0; kt < nkt; ++kt) {
-    const char* cur = smem + (kt & 1) * Cfg::STAGE;
-    char* nxt = smem + ((kt + 1) & 1) * Cfg::STAGE;
-    const bool more = (kt + 1) < nkt;
-    if (more && !(DBG & 4)) gload(kt + 1);
-
-    // A wave whose 32 query rows all lie past Sq (the ragged last block of S = 1025: three of its four waves) only helps
-    // staging the K/V tiles: one wave-uniform branch around the whole compute segment (branches INSIDE it hurt scheduling).
-    if (wave_active) {
-    // ---- S^T = K · Q^T (two 32-key sub-tiles) ----
-    f32x16_t st[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
+    for (int i = 0; i < QW; ++i) {
+      const int qrow = q0 + 32 * i + l31;
+      const int off = (qrow < p.Sq) ? ((b * p.Sq + qrow) * p.ldq + head * D + 8 * hh) * 2 : -1;
+      drop_rh[i] = DROP ? drop_row_hash(p.drop, (unsigned)((b * p.H + head) * p.Sq + qrow)) : 0u;
 #pragma unroll
       for (int s = 0; s < NKS; ++s) {
-        bf16x8_t kf = *(const bf16x8_t*)(((DBG & 2) ? smem : cur) + k_frag + 32 * t * KS + 32 * s);
-        if (DBG & 2) { kf = qf[s]; asm volatile("" : "+v"(kf)); }
-        st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[t], 0, 0, 0);
+        const i32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsQ, off < 0 ? -1 : off + s * 32, 0, 0);
+        qf[i][s] = __builtin_bit_cast(bf16x8_t, v);
       }
     }
-
-    // ---- softmax update: interior tiles (no bias, no causal edge, full 64 keys) take a branch-free path with
-    // one fma + one exp per score; edge tiles take the general masked path ----
-    const bool tail = (kt * 64 + 64 > p.Sk);
-    const bool diag = p.causal && (kt * 64 + 63 > bx * 128);  // some key may exceed some query
-    const bool masked = tail || diag || (p.kbias != nullptr);
-    float alpha, psum = 0.f;
-    if (DBG & 1) {
-      alpha = 1.f;
-    } else if (!masked) {
-      float mx = st[0][0];
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[t][r]);
-      mx *= p.scale_log2;  // scale > 0
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx);
-      alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      m_run = m_new;
-      const float neg_m = -m_new;
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(st[t][r], p.scale_log2, neg_m));
-          st[t][r] = e;
-          psum += e;
-        }
-    } else {
-      const float* biasv = (const float*)(cur + Cfg::KT + Cfg::VT);
-      float mx = NEG_INF;
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const f32x4_t bz = *(const f32x4_t*)(biasv + 32 * t + 8 * c + 4 * hh);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float sc = st[t][4 * c + j] * p.scale_log2 + bz[j];
-            if (diag) {
-              const int key = kt * 64 + 32 * t + 8 * c + 4 * hh + j;
-              if (key > qrow) sc = NEG_INF;
-            }
-            st[t][4 * c + j] = sc;
-            mx = fmaxf(mx, sc);
-          }
-        }
-      }
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx);
-      const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
-      alpha = __builtin_amdgcn_exp2f(m_run - m_use);
-      m_run = m_new;
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float e = __builtin_amdgcn_exp2f(st[t][r] - m_use);
-          st[t][r] = e;
-          psum += e;
-        }
-    }
-    l_run = l_run * alpha + psum;
-    if constexpr (DROP) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const unsigned key = (unsigned)(kt * 64 + 32 * t + 8 * (r >> 2) + 4 * hh + (r & 3));
-          st[t][r] = drop_keep(p.drop, drop_rh, key) ? st[t][r] * p.drop.inv_keep : 0.f;
-        }
-    }
-    if (__any(alpha != 1.f)) {  // lazy rescale: once the running max has settled nothing is multiplied
-#pragma unroll
-      for (int d = 0; d < NDT; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ot[d][r] *= alpha;
-    }
-
-    // ---- O^T += V^T · P^T ----
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int t = ks >> 1, s2 = ks & 1;
-      bf16x8_t pf;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) pf[j] = (__bf16)st[t][8 * s2 + j];
-#pragma unroll
-      for (int d = 0; d < NDT; ++d) {
-        const int a = v_frag + (32 * t + 16 * s2) * VS + 64 * d;
-        bf16x8_t vf;
-        if (DBG & 2) { vf = qf[d]; asm volatile("" : "+v"(vf)); }
-        else vf = tr_frag2(cur + Cfg::KT, a, a + 8 * VS);
-        if (!(DBG & 8)) ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, ot[d], 0, 0, 0);
-        else ot[d][0] += (float)pf[0] + (float)vf[0];
-      }
-    }
-    }  // wave_active
-
-    if (more && !(DBG & 4)) lstore(nxt);
-    __syncthreads();
   }
 
-  // ---- normalise and store: lane = query, registers = 4-wide runs of d ----
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
-  if (qrow < p.Sq) {
-    bf16_t* orow = p.O + (size_t)(b * p.Sq + qrow) * p.ldo + head * D;
+  // fragment addresses in a stage (the swizzle only looks at row bits 0..3: 16- / 32-row steps are immediates on these bases)
+  const int q4 = (lane >> 2) & 3, p4 = lane & 3, cg = (lane >> 4) & 1;
+  int k_row[NKS], v_lo[NDT], v_hi[NDT];
+#pragma unroll
+  for (int s = 0; s < NKS; ++s) k_row[s] = Cfg::off(l31, 2 * s + hh);          // + 32t*PITCH
+#pragma unroll
+  for (int d = 0; d < NDT; ++d) {
+    const int e = 32 * d + 16 * cg + 4 * p4;
+    v_lo[d] = Cfg::TILE + Cfg::off(4 * hh + q4, e >> 3) + (e & 7) * 2;        // + (32t + 16 s2)*PITCH
+    v_hi[d] = Cfg::TILE + Cfg::off(4 * hh + q4 + 8, e >> 3) + (e & 7) * 2;
+  }
+
+  f32x16_t ot[QW][NDT];
+  float lsum[QW], m_ref[QW];   // lsum: this lane's share of the row sum (its 32 keys per tile); m_ref: the row's frame
+  bool counted[QW];            // has the row met an unmasked key (its frame is then a real score's maximum)
+#pragma unroll
+  for (int i = 0; i < QW; ++i) {
+#pragma unroll
+    for (int d = 0; d < NDT; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ot[i][d][r] = 0.f;
+    lsum[i] = 0.f; m_ref[i] = 0.f; counted[i] = false;
+  }
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    // tile kt has landed once all but the DMAs of the (at most PD-1) younger tiles of THIS wave are done; the barrier then
+    // publishes every wave's pieces and, at the same time, retires all reads of the slot that is re-filled next
+    if (kt + PD - 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::IPT * (PD - 1)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + PD < nkt) request(kt + PD);
+    // per-tile fragment bases (ring slot + per-lane swizzled offset), made opaque so that hipcc keeps ONE register per base and
+    // folds the 16- / 32-row steps into the ds_read offset fields (it otherwise hoists 16 pre-added addresses and spills them)
+    const int so = (kt % NSTAGE) * Cfg::STAGE;
+    int kb[NKS], vl[NDT], vh[NDT];
+#pragma unroll
+    for (int s2 = 0; s2 < NKS; ++s2) { kb[s2] = so + k_row[s2]; asm volatile("" : "+v"(kb[s2])); }
+#pragma unroll
+    for (int d = 0; d < NDT; ++d) {
+      vl[d] = so + v_lo[d]; vh[d] = so + v_hi[d];
+      asm volatile("" : "+v"(vl[d]), "+v"(vh[d]));
+    }
+
+    if (wave_active) {   // waves wholly past Sq (ragged last block) only help staging
+    const bool tail = (kt * 64 + 64 > p.Sk);
+    const bool diag = p.causal && (kt * 64 + 63 > bx * QB);  // some key may exceed some query
+    const bool masked = tail || diag || (p.kbias != nullptr);
+    // the 64-key tile is consumed as two 32-key halves (t): the score registers of only one half are live at a time
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+    f32x16_t st[QW];
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+      // ---- S^T = K · Q^T (32 keys x QW query sub-tiles), then s' = S^T * scale*log2(e) - m_ref in fp32 ----
+#pragma unroll
+      for (int i = 0; i < QW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[i][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < NKS; ++s) {
+        const bf16x8_t kf = *(const bf16x8_t*)(smem + kb[s] + 32 * t * PITCH);
+#pragma unroll
+        for (int i = 0; i < QW; ++i) st[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[i][s], st[i], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < QW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[i][r] = __builtin_fmaf(st[i][r], p.scale_log2, -m_ref[i]);
+      if (masked) {   // key tail / key padding / causal edge: -inf (or the additive key bias) per score
+        int key0 = kt * 64 + 32 * t + 4 * hh, qb0 = q0 + l31;
+        asm volatile("" : "+v"(key0), "+v"(qb0));   // keeps the per-score compares INSIDE this branch (hipcc hoists them otherwise)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int key = key0 + 8 * c + j;
+            float kb = 0.f;
+            if (key >= p.Sk) kb = NEG_INF;                                                  // key tail (the tile's zero rows)
+            else if (p.kbias) kb = p.kbias[(size_t)b * p.Sk + key] * 1.44269504088896341f;  // 0 / -inf key padding
+#pragma unroll
+            for (int i = 0; i < QW; ++i) {
+              float sc = st[i][4 * c + j] + kb;
+              if (diag && key > qb0 + 32 * i) sc = NEG_INF;
+              st[i][4 * c + j] = sc;
+            }
+          }
+      }
+      // per-lane maxima of the lane's 16 keys (no exchange with the other half on the common path)
+      float mx[QW];
+      bool rare = (kt == 0 && t == 0);
+#pragma unroll
+      for (int i = 0; i < QW; ++i) {
+        float ma = max3f(st[i][0], st[i][1], st[i][2]), mb = max3f(st[i][3], st[i][4], st[i][5]);
+        ma = max3f(ma, st[i][6], st[i][7]);
+        mb = max3f(mb, st[i][8], st[i][9]);
+        ma = max3f(ma, st[i][10], st[i][11]);
+        mb = max3f(mb, st[i][12], st[i][13]);
+        mx[i] = max3f(ma, mb, fmaxf(st[i][14], st[i][15]));
+        rare = rare || (mx[i] > FRAME_THR) || (!counted[i] && mx[i] > NEG_INF);
+      }
+      if (pass == 1 || !__any(rare)) break;
+      // ---- rare: some row outgrew its frame (or met its first key).  Move those rows, redo the chain in the new frames ----
+#pragma unroll
+      for (int i = 0; i < QW; ++i) {
+        const float mxx = fmaxf(mx[i], __shfl_xor(mx[i], 32, 64));          // the row's maximum over both lane halves
+        const bool move = (mxx > FRAME_THR) || (!counted[i] && mxx > NEG_INF);
+        const float m_new = move ? m_ref[i] + mxx : m_ref[i];
+        const float corr = __builtin_amdgcn_exp2f(m_ref[i] - m_new);        // 1 where nothing moves; O, l are 0 before the first key
+#pragma unroll
+        for (int d = 0; d < NDT; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ot[i][d][r] *= corr;
+        lsum[i] *= corr;
+        m_ref[i] = m_new;
+        counted[i] = counted[i] || (mxx > NEG_INF);
+      }
+    }
+    // ---- P = exp2(S - m_ref); row sums; O^T += V^T · P^T ----
+#pragma unroll
+    for (int i = 0; i < QW; ++i) {
+      float ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        st[i][r] = __builtin_amdgcn_exp2f(st[i][r]);
+        ps += st[i][r];
+      }
+      lsum[i] += ps;
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8_t pf[QW];
+#pragma unroll
+      for (int i = 0; i < QW; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int r = 8 * s2 + j;
+          float pv = st[i][r];
+          if constexpr (DROP) {
+            const unsigned key = (unsigned)(kt * 64 + 32 * t + 8 * (r >> 2) + 4 * hh + (r & 3));
+            pv = drop_keep(p.drop, drop_rh[i], key) ? pv * p.drop.inv_keep : 0.f;
+          }
+          pf[i][j] = (__bf16)pv;
+        }
+#pragma unroll
+      for (int d = 0; d < NDT; ++d) {
+        const int roff = (32 * t + 16 * s2) * PITCH;
+        const bf16x8_t vf = tr_frag2(smem, vl[d] + roff, vh[d] + roff);
+#pragma unroll
+        for (int i = 0; i < QW; ++i) ot[i][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[i], ot[i][d], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);   // halves are not interleaved by the scheduler (it would need ~30 more registers than exist)
+    }  // t
+    }  // wave_active
+  }
+
+  // ---- normalise; O goes out through LDS as whole rows (the ring is free: every DMA has landed and been consumed) ----
+  __builtin_amdgcn_s_barrier();   // all waves are past their last reads of the ring
+  char* obuf = smem + wid * (32 * QW * OP);
+#pragma unroll
+  for (int i = 0; i < QW; ++i) {
+    const float l_tot = lsum[i] + __shfl_xor(lsum[i], 32, 64);
+    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+    const int qrow = q0 + 32 * i + l31;
+    if (p.lse2 && hh == 0 && qrow < p.Sq)
+      p.lse2[((size_t)b * p.H + head) * p.Sq + qrow] = l_tot > 0.f ? m_ref[i] + __builtin_amdgcn_logf(l_tot) : NEG_INF;
 #pragma unroll
     for (int d = 0; d < NDT; ++d)
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int col = 32 * d + 8 * c + 4 * hh;
-        uint2 pk = make_uint2(pack_bf16x2(ot[d][4 * c] * inv, ot[d][4 * c + 1] * inv),
-                              pack_bf16x2(ot[d][4 * c + 2] * inv, ot[d][4 * c + 3] * inv));
-        *reinterpret_cast<uint2*>(orow + col) = pk;
+        *(uint2*)(obuf + (32 * i + l31) * OP + col * 2) =
+            make_uint2(pack_bf16x2(ot[i][d][4 * c] * inv, ot[i][d][4 * c + 1] * inv),
+                       pack_bf16x2(ot[i][d][4 * c + 2] * inv, ot[i][d][4 * c + 3] * inv));
       }
-    if (p.lse2 && hh == 0)
-      p.lse2[((size_t)b * p.H + head) * p.Sq + qrow] =
-          l_tot > 0.f ? m_run + __builtin_amdgcn_logf(l_tot) : NEG_INF;
+  }
+  // (each wave reads back only what it wrote: no barrier, the compiler's lgkmcnt wait orders the LDS accesses of one wave)
+  {
+    constexpr int CPR = D / 8;                   // 16-byte chunks per output row
+    constexpr int RPI = 64 / CPR;                // rows per store instruction (lanes of one row are contiguous: a whole row segment)
+    const __amdgpu_buffer_rsrc_t rsO = make_rsrc(p.O, (unsigned)p.B * p.Sq * p.ldo * 2u);
+    const int r_in = lane / CPR, ch = lane % CPR;
+    if (lane < RPI * CPR) {
+#pragma unroll
+      for (int it = 0; it < 32 * QW / RPI + (32 * QW % RPI ? 1 : 0); ++it) {
+        const int row = it * RPI + r_in;
+        if (row < 32 * QW) {
+          const i32x4_t v = *(const i32x4_t*)(obuf + row * OP + ch * 16);
+          const int qrow = q0 + row;
+          const int off = (qrow < p.Sq) ? ((b * p.Sq + qrow) * p.ldo + head * D + ch * 8) * 2 : -1;
+          __builtin_amdgcn_raw_buffer_store_b128(v, rsO, off, 0, 0);
+        }
+      }
+    }
   }
 }
 
-template <int D, int DBG = 0, bool DROP = false>
+template <int D, int QW, bool DROP>
 int launch_attn_fwd(const AttnFwdArgs& a, hipStream_t stream) {
   using Cfg = AttnCfg<D>;
-  auto kern = attn_fwd_kernel<D, DBG, DROP>;
+  auto kern = attn_fwd_kernel<D, QW, DROP>;
+  constexpr int OBUF = 4 * 32 * QW * (2 * D + 16);
+  constexpr int LDS = Cfg::NSTAGE * Cfg::STAGE > OBUF ? Cfg::NSTAGE * Cfg::STAGE : OBUF;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Cfg::STAGE) !=
-        hipSuccess)
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
       return LC2IS_ERR_LAUNCH;
     attr_set = true;
   }
-  static const int lds_pad = getenv("LC2IS_ATTN_LDS_PAD") ? atoi(getenv("LC2IS_ATTN_LDS_PAD")) : 0;   // occupancy probe (tools/attn_ablate.py)
-  if (lds_pad) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Cfg::STAGE + lds_pad);
-  hipLaunchKernelGGL(kern, dim3(((a.Sq + 127) / 128) * a.H * a.B), dim3(256), 2 * Cfg::STAGE + lds_pad, stream, a);
+  hipLaunchKernelGGL(kern, dim3(((a.Sq + 128 * QW - 1) / (128 * QW)) * a.H * a.B), dim3(256), LDS, stream, a);
   return lc2is_check_launch();
 }
 
@@ -336,28 +410,19 @@ static int attention_fwd_impl(const void* Q, int ldq, const void* K, int ldk, co
   if (a.drop.thr) {
     if ((double)B * H * Sq >= 4294967296.0) return LC2IS_ERR_UNSUPPORTED;   // 32-bit row coordinate of the RNG
     switch (D) {
-      case 64: return launch_attn_fwd<64, 0, true>(a, stream);
-      case 96: return launch_attn_fwd<96, 0, true>(a, stream);
-      case 128: return launch_attn_fwd<128, 0, true>(a, stream);
+      case 64: return launch_attn_fwd<64, 1, true>(a, stream);
+      case 96: return launch_attn_fwd<96, 1, true>(a, stream);
+      case 128: return launch_attn_fwd<128, 1, true>(a, stream);
       default: return LC2IS_ERR_UNSUPPORTED;
     }
   }
   switch (D) {
     case 64: {
-      static const int dbg = getenv("LC2IS_ATTN_DBG") ? atoi(getenv("LC2IS_ATTN_DBG")) : 0;
-      switch (dbg) {
-        case 1: return launch_attn_fwd<64, 1>(a, stream);
-        case 2: return launch_attn_fwd<64, 2>(a, stream);
-        case 4: return launch_attn_fwd<64, 4>(a, stream);
-        case 6: return launch_attn_fwd<64, 6>(a, stream);
-        case 7: return launch_attn_fwd<64, 7>(a, stream);
-        case 8: return launch_attn_fwd<64, 8>(a, stream);
-        case 15: return launch_attn_fwd<64, 15>(a, stream);
-        default: return launch_attn_fwd<64>(a, stream);
-      }
+      static const int qw = getenv("LC2IS_ATTN_QW") ? atoi(getenv("LC2IS_ATTN_QW")) : 1;   // A/B: queries per wave / 32
+      return qw == 2 ? launch_attn_fwd<64, 2, false>(a, stream) : launch_attn_fwd<64, 1, false>(a, stream);
     }
-    case 96: return launch_attn_fwd<96>(a, stream);
-    case 128: return launch_attn_fwd<128>(a, stream);
+    case 96: return launch_attn_fwd<96, 1, false>(a, stream);
+    case 128: return launch_attn_fwd<128, 1, false>(a, stream);
     default: return LC2IS_ERR_UNSUPPORTED;
   }
 }
