@@ -88,18 +88,22 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
   return d;
 }
 
-// Structure (S = 1025, D = 64 measured on MI355X, rocprofv3 + ablation builds of the round-1 form: 28 % of the launch was per-block
-// prologue / epilogue latency and the key loop ran at ~600 cycles per 64-key wave-tile for 512 cycles of MFMA work because
-// each wave is one serial chain  QK^T -> max -> lane exchange -> branch -> exp2 -> P.V  with 2-3 waves per SIMD to hide it):
-//  * a wave owns QW x 32 queries (QW = 2 at D = 64): two independent chains per wave, every K and V^T fragment read from LDS
-//    feeds two MFMAs, and a block (4 waves) amortises its prologue / epilogue and its K/V stream over 256 queries;
-//  * K/V tiles arrive by LDS-DMA into a ring (3 deep at D = 64) behind counted s_waitcnt vmcnt + one raw s_barrier per tile;
-//  * every row keeps its state (O, l) in a FRAME m_ref: O = sum_k exp2(s_k - m_ref) v_k.  A tile adds exp2(s - m_ref) in the
+// Structure.  Measured on MI355X at S = 1025, D = 64 (rocprofv3 SQ counters, s_memtime phase stamps — tools/attn_stamp.sh —
+// and key-length sweeps — tools/attn_fixedcost.py): the launch costs 20 us + 8.25 us per 64-key tile, and a wave of the
+// un-pipelined form spends 3300 cycles per tile of which 2070 sit in ONE serial chain
+//     ds_read K -> 4 dependent MFMAs -> scale -> max -> branch -> exp2 -> pack -> ds_read V^T -> P.V
+// that hipcc cannot overlap because the frame check splits it into basic blocks; three such waves keep the matrix pipe 47 % busy.
+//  * software pipeline over 32-key HALF tiles: the S^T chain of half h+1 (LDS reads + MFMAs) is issued in the same basic block
+//    as exp2 / row sums / pack / V^T reads / P.V of half h, so its latency runs under the VALU work and vice versa; the only
+//    branch of a half step — the frame check — sits at the block boundary in front of it;
+//  * K/V tiles arrive by LDS-DMA into a ring (3 deep at D = 64) behind counted s_waitcnt vmcnt + one raw s_barrier per tile,
+//    placed in the middle of a tile's two half steps (where the next tile's first S^T chain needs its data);
+//  * every row keeps its state (O, l) in a FRAME m_ref: O = sum_k exp2(s_k - m_ref) v_k.  A half tile adds exp2(s - m_ref) in the
 //    same frame, so nothing is rescaled and the lane halves that share a row do not talk to each other.  Only when some row's
-//    tile maximum exceeds its frame by more than FRAME_THR (or a row meets its first unmasked key) the wave takes a rare branch:
-//    the halves exchange their maxima, the row moves to the frame of its new maximum (O, l times exp2(m_ref - m_ref')), and
-//    the S^T chain of this tile is redone in the new frame.  Probabilities are therefore <= 2^FRAME_THR and >= their true
-//    value relative to a real score: no overflow, no row-wide underflow;
+//    half-tile maximum exceeds its frame by more than FRAME_THR (or a row meets its first unmasked key) the wave takes the rare
+//    branch: the halves exchange their maxima, the row moves to the frame of its new maximum (O, l times exp2(m_ref - m_ref'),
+//    the waiting scores shifted by the same amount).  Probabilities are <= 2^FRAME_THR and a row's frame is always the
+//    maximum of real scores: no overflow, no row-wide underflow;
 //  * a score costs one fma (scale and frame), half a max3, one exp2, one add and half a pack (tried and dropped: Q pre-multiplied
 //    by scale*log2(e) in bf16 with -m_ref fed through an extra MFMA saves the fma but rounds Q once more — 2-3e-3 on scores and
 //    log-sum-exp — and measured no faster);
@@ -109,12 +113,12 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
 // coordinate of a score = (row (b*H + h)*Sq + q, column key), so the backward kernels regenerate the same decisions.
 constexpr float FRAME_THR = 6.0f;
 
-template <int D, int QW, bool DROP>
-__global__ __launch_bounds__(256, (D == 64 && QW == 1) ? 3 : 2) void attn_fwd_kernel(AttnFwdArgs p) {
+template <int D, bool DROP>
+__global__ __launch_bounds__(256, (D == 64) ? 3 : 2) void attn_fwd_kernel(AttnFwdArgs p) {
   using Cfg = AttnCfg<D>;
   constexpr int PITCH = Cfg::PITCH, NSTAGE = Cfg::NSTAGE, PD = NSTAGE - 1;
   constexpr int NKS = D / 16, NDT = D / 32;
-  constexpr int QB = 128 * QW;          // queries per block
+  constexpr int QB = 128;               // queries per block (4 waves x 32)
   constexpr int OP = 2 * D + 16;        // row pitch of the output staging image (bytes)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -126,8 +130,9 @@ __global__ __launch_bounds__(256, (D == 64 && QW == 1) ? 3 : 2) void attn_fwd_ke
   const int nqb = (p.Sq + QB - 1) / QB;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int bx = tile % nqb, head = (tile / nqb) % p.H, b = tile / (nqb * p.H);
-  const int q0 = bx * QB + wid * 32 * QW;            // first query of this wave
-  const bool wave_active = q0 < p.Sq;                 // wave-uniform; later sub-tiles of a ragged wave compute on zero rows
+  const int q0 = bx * QB + wid * 32;                  // first query of this wave
+  const int qrow = q0 + l31;
+  const bool wave_active = q0 < p.Sq;                 // wave-uniform; waves wholly past Sq only help staging
   const float NEG_INF = -__builtin_inff();
 
   int nkt = (p.Sk + 63) / 64;
@@ -158,23 +163,16 @@ __global__ __launch_bounds__(256, (D == 64 && QW == 1) ? 3 : 2) void attn_fwd_ke
   for (int i = 0; i < PD; ++i)
     if (i < nkt) request(i);
 
-  // Q fragments (B operand of S^T = K·Q^T): lane holds Q[q][16s + 8hh .. +7] of its QW queries
-  bf16x8_t qf[QW][NKS];
-  unsigned drop_rh[QW];
+  // Q fragments (B operand of S^T = K·Q^T): lane holds Q[qrow][16s + 8hh .. +7]
+  bf16x8_t qf[NKS];
   {
     const __amdgpu_buffer_rsrc_t rsQ = make_rsrc(p.Q, qbytes);
+    const int off = (qrow < p.Sq) ? ((b * p.Sq + qrow) * p.ldq + head * D + 8 * hh) * 2 : -1;
 #pragma unroll
-    for (int i = 0; i < QW; ++i) {
-      const int qrow = q0 + 32 * i + l31;
-      const int off = (qrow < p.Sq) ? ((b * p.Sq + qrow) * p.ldq + head * D + 8 * hh) * 2 : -1;
-      drop_rh[i] = DROP ? drop_row_hash(p.drop, (unsigned)((b * p.H + head) * p.Sq + qrow)) : 0u;
-#pragma unroll
-      for (int s = 0; s < NKS; ++s) {
-        const i32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsQ, off < 0 ? -1 : off + s * 32, 0, 0);
-        qf[i][s] = __builtin_bit_cast(bf16x8_t, v);
-      }
-    }
+    for (int s = 0; s < NKS; ++s)
+      qf[s] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rsQ, off < 0 ? -1 : off + s * 32, 0, 0));
   }
+  const unsigned drop_rh = DROP ? drop_row_hash(p.drop, (unsigned)((b * p.H + head) * p.Sq + qrow)) : 0u;
 
   // fragment addresses in a stage (the swizzle only looks at row bits 0..3: 16- / 32-row steps are immediates on these bases)
   const int q4 = (lane >> 2) & 3, p4 = lane & 3, cg = (lane >> 4) & 1;
@@ -188,168 +186,161 @@ __global__ __launch_bounds__(256, (D == 64 && QW == 1) ? 3 : 2) void attn_fwd_ke
     v_hi[d] = Cfg::TILE + Cfg::off(4 * hh + q4 + 8, e >> 3) + (e & 7) * 2;
   }
 
-  f32x16_t ot[QW][NDT];
-  float lsum[QW], m_ref[QW];   // lsum: this lane's share of the row sum (its 32 keys per tile); m_ref: the row's frame
-  bool counted[QW];            // has the row met an unmasked key (its frame is then a real score's maximum)
+  f32x16_t ot[NDT];
 #pragma unroll
-  for (int i = 0; i < QW; ++i) {
+  for (int d = 0; d < NDT; ++d)
 #pragma unroll
-    for (int d = 0; d < NDT; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ot[i][d][r] = 0.f;
-    lsum[i] = 0.f; m_ref[i] = 0.f; counted[i] = false;
-  }
+    for (int r = 0; r < 16; ++r) ot[d][r] = 0.f;
+  float lsum = 0.f, m_ref = 0.f;   // lsum: this lane's share of the row sum (its 16 keys per half tile); m_ref: the row's frame
+  bool counted = false;            // has the row met an unmasked key (its frame is then a real score's maximum)
 
-  for (int kt = 0; kt < nkt; ++kt) {
-    // tile kt has landed once all but the DMAs of the (at most PD-1) younger tiles of THIS wave are done; the barrier then
-    // publishes every wave's pieces and, at the same time, retires all reads of the slot that is re-filled next
-    if (kt + PD - 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::IPT * (PD - 1)) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (kt + PD < nkt) request(kt + PD);
-    // per-tile fragment bases (ring slot + per-lane swizzled offset), made opaque so that hipcc keeps ONE register per base and
-    // folds the 16- / 32-row steps into the ds_read offset fields (it otherwise hoists 16 pre-added addresses and spills them)
-    const int so = (kt % NSTAGE) * Cfg::STAGE;
-    int kb[NKS], vl[NDT], vh[NDT];
+  // S^T = K · Q^T of one 32-key half tile (raw, unscaled): 4 (D/16) LDS row reads + dependent MFMAs
+  auto issue_s = [&](int so, int t, f32x16_t& st) {
 #pragma unroll
-    for (int s2 = 0; s2 < NKS; ++s2) { kb[s2] = so + k_row[s2]; asm volatile("" : "+v"(kb[s2])); }
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
 #pragma unroll
-    for (int d = 0; d < NDT; ++d) {
-      vl[d] = so + v_lo[d]; vh[d] = so + v_hi[d];
-      asm volatile("" : "+v"(vl[d]), "+v"(vh[d]));
+    for (int s = 0; s < NKS; ++s) {
+      const bf16x8_t kf = *(const bf16x8_t*)(smem + so + k_row[s] + 32 * t * PITCH);
+      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st, 0, 0, 0);
     }
-
-    if (wave_active) {   // waves wholly past Sq (ragged last block) only help staging
+  };
+  // block 1 of a half step: scale into the row's frame, masks, per-lane maximum, frame check (the only branch)
+  auto frame = [&](f32x16_t& st, int kt, int t) {
     const bool tail = (kt * 64 + 64 > p.Sk);
     const bool diag = p.causal && (kt * 64 + 63 > bx * QB);  // some key may exceed some query
-    const bool masked = tail || diag || (p.kbias != nullptr);
-    // the 64-key tile is consumed as two 32-key halves (t): the score registers of only one half are live at a time
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-    f32x16_t st[QW];
-#pragma unroll 1
-    for (int pass = 0; pass < 2; ++pass) {
-      // ---- S^T = K · Q^T (32 keys x QW query sub-tiles), then s' = S^T * scale*log2(e) - m_ref in fp32 ----
+    for (int r = 0; r < 16; ++r) st[r] = __builtin_fmaf(st[r], p.scale_log2, -m_ref);
+    if (tail || diag || p.kbias != nullptr) {   // key tail / key padding / causal edge: -inf (or the additive key bias) per score
+      int key0 = kt * 64 + 32 * t + 4 * hh, qr = qrow;
+      asm volatile("" : "+v"(key0), "+v"(qr));   // keeps the per-score compares INSIDE this branch (hipcc hoists them otherwise)
 #pragma unroll
-      for (int i = 0; i < QW; ++i)
+      for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) st[i][r] = 0.f;
-#pragma unroll
-      for (int s = 0; s < NKS; ++s) {
-        const bf16x8_t kf = *(const bf16x8_t*)(smem + kb[s] + 32 * t * PITCH);
-#pragma unroll
-        for (int i = 0; i < QW; ++i) st[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[i][s], st[i], 0, 0, 0);
-      }
-#pragma unroll
-      for (int i = 0; i < QW; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) st[i][r] = __builtin_fmaf(st[i][r], p.scale_log2, -m_ref[i]);
-      if (masked) {   // key tail / key padding / causal edge: -inf (or the additive key bias) per score
-        int key0 = kt * 64 + 32 * t + 4 * hh, qb0 = q0 + l31;
-        asm volatile("" : "+v"(key0), "+v"(qb0));   // keeps the per-score compares INSIDE this branch (hipcc hoists them otherwise)
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int key = key0 + 8 * c + j;
-            float kb = 0.f;
-            if (key >= p.Sk) kb = NEG_INF;                                                  // key tail (the tile's zero rows)
-            else if (p.kbias) kb = p.kbias[(size_t)b * p.Sk + key] * 1.44269504088896341f;  // 0 / -inf key padding
-#pragma unroll
-            for (int i = 0; i < QW; ++i) {
-              float sc = st[i][4 * c + j] + kb;
-              if (diag && key > qb0 + 32 * i) sc = NEG_INF;
-              st[i][4 * c + j] = sc;
-            }
-          }
-      }
-      // per-lane maxima of the lane's 16 keys (no exchange with the other half on the common path)
-      float mx[QW];
-      bool rare = (kt == 0 && t == 0);
-#pragma unroll
-      for (int i = 0; i < QW; ++i) {
-        float ma = max3f(st[i][0], st[i][1], st[i][2]), mb = max3f(st[i][3], st[i][4], st[i][5]);
-        ma = max3f(ma, st[i][6], st[i][7]);
-        mb = max3f(mb, st[i][8], st[i][9]);
-        ma = max3f(ma, st[i][10], st[i][11]);
-        mb = max3f(mb, st[i][12], st[i][13]);
-        mx[i] = max3f(ma, mb, fmaxf(st[i][14], st[i][15]));
-        rare = rare || (mx[i] > FRAME_THR) || (!counted[i] && mx[i] > NEG_INF);
-      }
-      if (pass == 1 || !__any(rare)) break;
-      // ---- rare: some row outgrew its frame (or met its first key).  Move those rows, redo the chain in the new frames ----
-#pragma unroll
-      for (int i = 0; i < QW; ++i) {
-        const float mxx = fmaxf(mx[i], __shfl_xor(mx[i], 32, 64));          // the row's maximum over both lane halves
-        const bool move = (mxx > FRAME_THR) || (!counted[i] && mxx > NEG_INF);
-        const float m_new = move ? m_ref[i] + mxx : m_ref[i];
-        const float corr = __builtin_amdgcn_exp2f(m_ref[i] - m_new);        // 1 where nothing moves; O, l are 0 before the first key
-#pragma unroll
-        for (int d = 0; d < NDT; ++d)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) ot[i][d][r] *= corr;
-        lsum[i] *= corr;
-        m_ref[i] = m_new;
-        counted[i] = counted[i] || (mxx > NEG_INF);
-      }
+        for (int j = 0; j < 4; ++j) {
+          const int key = key0 + 8 * c + j;
+          float sc = st[4 * c + j];
+          if (key >= p.Sk) sc = NEG_INF;                                                       // key tail (the tile's zero rows)
+          else if (p.kbias) sc += p.kbias[(size_t)b * p.Sk + key] * 1.44269504088896341f;      // 0 / -inf key padding
+          if (diag && key > qr) sc = NEG_INF;
+          st[4 * c + j] = sc;
+        }
     }
-    // ---- P = exp2(S - m_ref); row sums; O^T += V^T · P^T ----
+    float ma = max3f(st[0], st[1], st[2]), mb = max3f(st[3], st[4], st[5]);
+    ma = max3f(ma, st[6], st[7]);
+    mb = max3f(mb, st[8], st[9]);
+    ma = max3f(ma, st[10], st[11]);
+    mb = max3f(mb, st[12], st[13]);
+    const float mx = max3f(ma, mb, fmaxf(st[14], st[15]));
+    if (__any((mx > FRAME_THR) || (!counted && mx > NEG_INF))) {
+      // rare: some row outgrew its frame (or met its first key): move those rows to the frame of their new maximum
+      const float mxx = fmaxf(mx, __shfl_xor(mx, 32, 64));            // the row's maximum over both lane halves
+      const bool move = (mxx > FRAME_THR) || (!counted && mxx > NEG_INF);
+      const float delta = move ? mxx : 0.f;
+      const float corr = __builtin_amdgcn_exp2f(-delta);             // 1 where nothing moves; O, l are 0 before the first key
 #pragma unroll
-    for (int i = 0; i < QW; ++i) {
-      float ps = 0.f;
+      for (int d = 0; d < NDT; ++d)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        st[i][r] = __builtin_amdgcn_exp2f(st[i][r]);
-        ps += st[i][r];
-      }
-      lsum[i] += ps;
+        for (int r = 0; r < 16; ++r) ot[d][r] *= corr;
+      lsum *= corr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[r] -= delta;
+      m_ref += delta;
+      counted = counted || (mxx > NEG_INF);
     }
+  };
+  // block 2 of a half step: P = exp2(s - m_ref), row sums, pack, O^T += V^T · P^T   (+ the next half's S^T chain, see the loop)
+  auto finish = [&](f32x16_t& st, int so, int kt, int t) {
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      st[r] = __builtin_amdgcn_exp2f(st[r]);
+      ps += st[r];
+    }
+    lsum += ps;
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
-      bf16x8_t pf[QW];
+      bf16x8_t pf;
 #pragma unroll
-      for (int i = 0; i < QW; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int r = 8 * s2 + j;
-          float pv = st[i][r];
-          if constexpr (DROP) {
-            const unsigned key = (unsigned)(kt * 64 + 32 * t + 8 * (r >> 2) + 4 * hh + (r & 3));
-            pv = drop_keep(p.drop, drop_rh[i], key) ? pv * p.drop.inv_keep : 0.f;
-          }
-          pf[i][j] = (__bf16)pv;
+      for (int j = 0; j < 8; ++j) {
+        const int r = 8 * s2 + j;
+        float pv = st[r];
+        if constexpr (DROP) {
+          const unsigned key = (unsigned)(kt * 64 + 32 * t + 8 * (r >> 2) + 4 * hh + (r & 3));
+          pv = drop_keep(p.drop, drop_rh, key) ? pv * p.drop.inv_keep : 0.f;
         }
+        pf[j] = (__bf16)pv;
+      }
 #pragma unroll
       for (int d = 0; d < NDT; ++d) {
-        const int roff = (32 * t + 16 * s2) * PITCH;
-        const bf16x8_t vf = tr_frag2(smem, vl[d] + roff, vh[d] + roff);
-#pragma unroll
-        for (int i = 0; i < QW; ++i) ot[i][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[i], ot[i][d], 0, 0, 0);
+        const int roff = so + (32 * t + 16 * s2) * PITCH;
+        const bf16x8_t vf = tr_frag2(smem, v_lo[d] + roff, v_hi[d] + roff);
+        ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, ot[d], 0, 0, 0);
       }
     }
-    __builtin_amdgcn_sched_barrier(0);   // halves are not interleaved by the scheduler (it would need ~30 more registers than exist)
-    }  // t
-    }  // wave_active
+  };
+  auto land = [&]() {   // this wave's outstanding DMAs have landed, and behind the barrier so have every wave's
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+
+  f32x16_t sa, sb;   // raw scores of the half in progress / the half issued ahead
+  if constexpr (Cfg::NSTAGE >= 3) {
+    // ring of three: tile kt+1 is awaited in the MIDDLE of tile kt (its first S^T chain is issued under the second half of tile
+    // kt) and tile kt+2 is requested there, into the slot of tile kt-1 which every wave has left when it reaches that barrier
+    if (nkt > 0) {
+      land();
+      if (wave_active) issue_s(0, 0, sa);
+    }
+    for (int kt = 0; kt < nkt; ++kt) {
+      const int so = (kt % NSTAGE) * Cfg::STAGE, son = ((kt + 1) % NSTAGE) * Cfg::STAGE;
+      const bool more = kt + 1 < nkt;
+      if (wave_active) {
+        frame(sa, kt, 0);
+        issue_s(so, 1, sb);                   // second half of this tile, under the exp2 / P.V of the first
+        finish(sa, so, kt, 0);
+      }
+      if (more) {
+        land();
+        if (kt + 2 < nkt) request(kt + 2);
+      }
+      if (wave_active) {
+        frame(sb, kt, 1);
+        if (more) issue_s(son, 0, sa);        // first half of the next tile, under the exp2 / P.V of this one
+        finish(sb, so, kt, 1);
+      }
+    }
+  } else {
+    // ring of two (32-KiB stages at D >= 96): one barrier at the top of a tile, the next tile requested behind it
+    for (int kt = 0; kt < nkt; ++kt) {
+      const int so = (kt % NSTAGE) * Cfg::STAGE;
+      land();
+      if (kt + 1 < nkt) request(kt + 1);
+      if (wave_active) {
+        issue_s(so, 0, sa);
+        frame(sa, kt, 0);
+        issue_s(so, 1, sb);
+        finish(sa, so, kt, 0);
+        frame(sb, kt, 1);
+        finish(sb, so, kt, 1);
+      }
+    }
   }
 
   // ---- normalise; O goes out through LDS as whole rows (the ring is free: every DMA has landed and been consumed) ----
   __builtin_amdgcn_s_barrier();   // all waves are past their last reads of the ring
-  char* obuf = smem + wid * (32 * QW * OP);
-#pragma unroll
-  for (int i = 0; i < QW; ++i) {
-    const float l_tot = lsum[i] + __shfl_xor(lsum[i], 32, 64);
+  char* obuf = smem + wid * (32 * OP);
+  {
+    const float l_tot = lsum + __shfl_xor(lsum, 32, 64);
     const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
-    const int qrow = q0 + 32 * i + l31;
     if (p.lse2 && hh == 0 && qrow < p.Sq)
-      p.lse2[((size_t)b * p.H + head) * p.Sq + qrow] = l_tot > 0.f ? m_ref[i] + __builtin_amdgcn_logf(l_tot) : NEG_INF;
+      p.lse2[((size_t)b * p.H + head) * p.Sq + qrow] = l_tot > 0.f ? m_ref + __builtin_amdgcn_logf(l_tot) : NEG_INF;
 #pragma unroll
     for (int d = 0; d < NDT; ++d)
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int col = 32 * d + 8 * c + 4 * hh;
-        *(uint2*)(obuf + (32 * i + l31) * OP + col * 2) =
-            make_uint2(pack_bf16x2(ot[i][d][4 * c] * inv, ot[i][d][4 * c + 1] * inv),
-                       pack_bf16x2(ot[i][d][4 * c + 2] * inv, ot[i][d][4 * c + 3] * inv));
+        *(uint2*)(obuf + l31 * OP + col * 2) = make_uint2(pack_bf16x2(ot[d][4 * c] * inv, ot[d][4 * c + 1] * inv),
+                                                          pack_bf16x2(ot[d][4 * c + 2] * inv, ot[d][4 * c + 3] * inv));
       }
   }
   // (each wave reads back only what it wrote: no barrier, the compiler's lgkmcnt wait orders the LDS accesses of one wave)
@@ -360,12 +351,12 @@ __global__ __launch_bounds__(256, (D == 64 && QW == 1) ? 3 : 2) void attn_fwd_ke
     const int r_in = lane / CPR, ch = lane % CPR;
     if (lane < RPI * CPR) {
 #pragma unroll
-      for (int it = 0; it < 32 * QW / RPI + (32 * QW % RPI ? 1 : 0); ++it) {
+      for (int it = 0; it < 32 / RPI + (32 % RPI ? 1 : 0); ++it) {
         const int row = it * RPI + r_in;
-        if (row < 32 * QW) {
+        if (row < 32) {
           const i32x4_t v = *(const i32x4_t*)(obuf + row * OP + ch * 16);
-          const int qrow = q0 + row;
-          const int off = (qrow < p.Sq) ? ((b * p.Sq + qrow) * p.ldo + head * D + ch * 8) * 2 : -1;
+          const int qr = q0 + row;
+          const int off = (qr < p.Sq) ? ((b * p.Sq + qr) * p.ldo + head * D + ch * 8) * 2 : -1;
           __builtin_amdgcn_raw_buffer_store_b128(v, rsO, off, 0, 0);
         }
       }
@@ -373,11 +364,11 @@ __global__ __launch_bounds__(256, (D == 64 && QW == 1) ? 3 : 2) void attn_fwd_ke
   }
 }
 
-template <int D, int QW, bool DROP>
+template <int D, bool DROP>
 int launch_attn_fwd(const AttnFwdArgs& a, hipStream_t stream) {
   using Cfg = AttnCfg<D>;
-  auto kern = attn_fwd_kernel<D, QW, DROP>;
-  constexpr int OBUF = 4 * 32 * QW * (2 * D + 16);
+  auto kern = attn_fwd_kernel<D, DROP>;
+  constexpr int OBUF = 4 * 32 * (2 * D + 16);
   constexpr int LDS = Cfg::NSTAGE * Cfg::STAGE > OBUF ? Cfg::NSTAGE * Cfg::STAGE : OBUF;
   static bool attr_set = false;
   if (!attr_set) {
@@ -385,7 +376,7 @@ int launch_attn_fwd(const AttnFwdArgs& a, hipStream_t stream) {
       return LC2IS_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(((a.Sq + 128 * QW - 1) / (128 * QW)) * a.H * a.B), dim3(256), LDS, stream, a);
+  hipLaunchKernelGGL(kern, dim3(((a.Sq + 127) / 128) * a.H * a.B), dim3(256), LDS, stream, a);
   return lc2is_check_launch();
 }
 
@@ -410,19 +401,16 @@ static int attention_fwd_impl(const void* Q, int ldq, const void* K, int ldk, co
   if (a.drop.thr) {
     if ((double)B * H * Sq >= 4294967296.0) return LC2IS_ERR_UNSUPPORTED;   // 32-bit row coordinate of the RNG
     switch (D) {
-      case 64: return launch_attn_fwd<64, 1, true>(a, stream);
-      case 96: return launch_attn_fwd<96, 1, true>(a, stream);
-      case 128: return launch_attn_fwd<128, 1, true>(a, stream);
+      case 64: return launch_attn_fwd<64, true>(a, stream);
+      case 96: return launch_attn_fwd<96, true>(a, stream);
+      case 128: return launch_attn_fwd<128, true>(a, stream);
       default: return LC2IS_ERR_UNSUPPORTED;
     }
   }
   switch (D) {
-    case 64: {
-      static const int qw = getenv("LC2IS_ATTN_QW") ? atoi(getenv("LC2IS_ATTN_QW")) : 1;   // A/B: queries per wave / 32
-      return qw == 2 ? launch_attn_fwd<64, 2, false>(a, stream) : launch_attn_fwd<64, 1, false>(a, stream);
-    }
-    case 96: return launch_attn_fwd<96, 1, false>(a, stream);
-    case 128: return launch_attn_fwd<128, 1, false>(a, stream);
+    case 64: return launch_attn_fwd<64, false>(a, stream);
+    case 96: return launch_attn_fwd<96, false>(a, stream);
+    case 128: return launch_attn_fwd<128, false>(a, stream);
     default: return LC2IS_ERR_UNSUPPORTED;
   }
 }
