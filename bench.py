@@ -220,8 +220,21 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     reducer = None
+    rccl_log = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl" and "NCCL_DEBUG" not in os.environ:
+            # record which algorithm / protocol RCCL picks over xGMI (ring vs tree / direct), per rank, into a file: the first
+            # real multi-GPU run then documents it (rank 0 quotes the lines in the JSON line's config.rccl)
+            out_dir = ROOT / "gpurun_out"
+            try:
+                out_dir.mkdir(exist_ok=True)
+                rccl_log = out_dir / f"rccl_rank{rank}.log"
+                os.environ["NCCL_DEBUG"] = "INFO"
+                os.environ["NCCL_DEBUG_SUBSYS"] = "INIT,TUNING,GRAPH"
+                os.environ["NCCL_DEBUG_FILE"] = str(rccl_log)
+            except OSError:
+                rccl_log = None
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -306,6 +319,13 @@ def main():
                          "avg_launch_us": gsum["seconds"] / max(gsum["launches"], 1) * 1e6,
                          "gemm_nt_time_share": gsum["seconds"] / timed_steps / (dt / args.steps)},
         }
+        if rccl_log is not None and rccl_log.exists():   # what RCCL chose (first lines that name an algorithm / channel count)
+            try:
+                picks = [ln.split("NCCL INFO", 1)[-1].strip() for ln in rccl_log.read_text(errors="replace").splitlines()
+                         if any(k in ln for k in ("Algo", "algo", "Ring ", "Tree ", "Channel", "nChannels", "xGMI", "XGMI"))]
+                out["config"]["rccl"] = picks[:6]
+            except OSError:
+                pass
         if not args.no_cpu_baseline and world == 1:   # the CPU baseline leg belongs to the N=1 line only
             try:
                 if args.patch != 16:

@@ -189,8 +189,15 @@ def _stack_bwd(g32, g16, stack: _Stack, sh, saved, a: ClipArch, B: int, S: int, 
     # weight gradients are deferred (base.WgradBatch) and leave as grouped launches, LC2IS_WGRAD_PAIR layers at a time.
     # Without a gradient reducer waiting on the layers (single GPU) the whole tower's weight gradients leave as ONE grid at the
     # end: 72 problems / 1296 tiles run as full-length blocks with ~97 % of the CUs busy, against 84 % for 216 blocks per layer.
-    # Under data parallelism the per-layer form stays, so that each layer's all-reduce starts as early as possible.
-    default_pair = 1 if (on_layer_done is not None or torch.cuda.is_current_stream_capturing()) else len(stack.layers)
+    # Under data parallelism three layers share a launch (324 tiles: 1 full round + a finely split tail round, planner cost
+    # 242 steps per layer against 287 for one layer and 225 for the tower) and report to the reducer together: its buckets
+    # are >= 48 MB (two layers) anyway, so the all-reduce of a group still starts under the backward of the next group.
+    if torch.cuda.is_current_stream_capturing():
+        default_pair = 1
+    elif on_layer_done is not None:
+        default_pair = min(3, len(stack.layers))
+    else:
+        default_pair = len(stack.layers)
     pair = int(__import__('os').environ.get('LC2IS_WGRAD_PAIR', str(default_pair)))
     batch, waiting = WgradBatch(), []
     batch.__enter__()

@@ -94,3 +94,25 @@ def test_two_rank_step_matches_global_batch(dev, tmp_path, backend):
     assert rel < 2e-2, rel   # different batch split -> different bf16 rounding, same gradient
     relp = ((p0 - ts.arena.flat.cpu()).norm() / (0.05 * gref.norm())).item()
     assert relp < 2e-2, relp
+
+
+def test_bench_two_ranks_gloo_end_to_end(dev, tmp_path):
+    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one rank per process), but with the gloo
+    backend and both ranks on the test box's one GPU: the whole DP path (parameter broadcast, per-group wgrad launches,
+    bucketed all-reduce from the backward callbacks, 1/world folded into the optimizer, barrier + MAX-over-ranks timing)
+    runs end to end and rank 0 prints ONE JSON line with the global batch and the dp2 label."""
+    import json
+    import subprocess
+    port = 29900 + os.getpid() % 1000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
+           "--in-size", "128", "--backend", "gloo", "--no-cpu-baseline"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 4 and rec["config"]["parallelism"] == "dp2"
+    assert rec["scaling"] == "weak" and rec["value"] > 0 and rec["final_loss"] == rec["final_loss"]
+    assert "cpu_baseline" not in rec                     # the CPU baseline belongs to the N = 1 line only
