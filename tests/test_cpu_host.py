@@ -185,5 +185,6 @@ def test_product_path_has_no_library_math():
         for n, line in enumerate(f.read_text().splitlines(), 1):
             code = line.split("#", 1)[0]
             if pat.search(code):
-                hits.append(f"{f.relative_to(root)}:{n}")
-    assert hits == ["nn/clip.py:310"], hits
+                hits.append((str(f.relative_to(root)), code.strip()))
+    # the one allowed use: pos_emebedding_interpolate's separable bicubic resize of the 14x14 position table at load time
+    assert len(hits) == 1 and hits[0][0] == "nn/clip.py" and "yi,ijc,xj->yxc" in hits[0][1], hits
