@@ -16,6 +16,7 @@
 // both by an XOR swizzle of the 16-byte chunk index (128-byte rows for D=64, 256-byte rows otherwise).
 #include "common.h"
 #include "lc2is_hip.h"
+#include <type_traits>
 
 namespace {
 
@@ -199,14 +200,18 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dq_kernel(Att
   }
   __syncthreads();
 
-  for (int kt = 0; kt < nkt; ++kt) {
+  // One tile of 64 keys.  MASKED is a compile-time property of the call site: the interior tiles of an unmasked launch (every
+  // tile of the vision tower but the last) run a body with NO control flow, which hipcc schedules as one block — the S^T / dP^T
+  // chains of the second 32-key half under the exp2 / dS arithmetic of the first; tail / key-padding / causal tiles take the
+  // general body (rocprofv3 SQ counters of the branchy form: VALU 45 % + MFMA 37 % busy, union 72 %: stalls between blocks).
+  auto tile_body = [&](int kt, auto masked_c) {
+    constexpr bool MASKED = decltype(masked_c)::value;
     const char* cur = smem + (kt & 1) * STAGE;
     char* nxt = smem + ((kt + 1) & 1) * STAGE;
     const bool more = (kt + 1) < nkt;
     if (more) gload(kt + 1);
     const float* biasv = (const float*)(cur + 2 * I::TILE);
-    const bool diag = p.causal && (kt * 64 + 63 > bx * 128);
-    const bool masked = diag || (kt * 64 + 64 > p.Sk) || (p.kbias != nullptr);
+    const bool diag = MASKED && p.causal && (kt * 64 + 63 > bx * 128);
 
     if (wave_active) {   // waves past Sq (ragged last block) only help staging: one wave-uniform branch around the compute
 #pragma unroll
@@ -229,7 +234,7 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dq_kernel(Att
           dpt[r] = drop_keep(p.drop, drop_rh, key) ? dpt[r] * p.drop.inv_keep : 0.f;
         }
       }
-      if (!masked) {  // interior tile: one fma + exp + sub + mul per score, no branches
+      if constexpr (!MASKED) {  // interior tile: one fma + exp + sub + mul per score, no branches
         const float neg_lse = -lse;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -266,7 +271,16 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dq_kernel(Att
     }  // wave_active
     if (more) lstore(nxt);
     __syncthreads();
+  };
+  // interior tiles first (full 64 keys, no bias, below the causal diagonal of every query of the block), then the rest
+  int n_plain = 0;
+  if (p.kbias == nullptr) {
+    n_plain = p.Sk / 64;                                   // tiles without a key tail
+    if (p.causal) { const int below = (bx * 128) / 64; if (below < n_plain) n_plain = below; }
+    if (n_plain > nkt) n_plain = nkt;
   }
+  for (int kt = 0; kt < n_plain; ++kt) tile_body(kt, std::false_type{});
+  for (int kt = n_plain; kt < nkt; ++kt) tile_body(kt, std::true_type{});
 
   if (qok) {
     bf16_t* row = p.dQ + (size_t)(b * p.Sq + qrow) * p.lddq + head * D;
@@ -385,7 +399,10 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(A
   }
   __syncthreads();
 
-  for (int qt = qt0; qt < nqt; ++qt) {
+  // One tile of 64 queries.  DIAG (some key of the block may exceed some query of the tile: causal launches only) is a
+  // compile-time property of the call site, so the non-causal body has no control flow (see the dQ kernel).
+  auto tile_body = [&](int qt, auto diag_c) {
+    constexpr bool DIAG = decltype(diag_c)::value;
     const int it = qt - qt0;
     const char* cur = smem + (it & 1) * STAGE;
     char* nxt = smem + ((it + 1) & 1) * STAGE;
@@ -393,7 +410,6 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(A
     if (more) gload(qt + 1);
     const float* lsev = (const float*)(cur + 2 * I::TILE);
     const float* delv = lsev + 64;
-    const bool diag = p.causal && (bx * 128 + 127 > qt * 64);  // some key may exceed some query
 
     if (wave_active) {   // waves past Sk (ragged last block) only help staging
 #pragma unroll
@@ -422,23 +438,16 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(A
             dp[4 * c + j] *= keep4[j];
           }
         }
-        if (!diag) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sa[4 * c + j], p.scale_log2, bias) - l4[j]);
-            sa[4 * c + j] = DROP ? pr * keep4[j] : pr;     // dV takes the dropped probabilities
-            dp[4 * c + j] = pr * (dp[4 * c + j] - d4[j]);
-          }
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float s2 = sa[4 * c + j] * p.scale_log2 + bias - l4[j];
+        for (int j = 0; j < 4; ++j) {
+          float s2 = __builtin_fmaf(sa[4 * c + j], p.scale_log2, bias) - l4[j];
+          if constexpr (DIAG) {
             const int q = qt * 64 + 32 * u + 8 * c + 4 * hh + j;
             if (kcol > q) s2 = -INF;
-            const float pr = __builtin_amdgcn_exp2f(s2);
-            sa[4 * c + j] = DROP ? pr * keep4[j] : pr;
-            dp[4 * c + j] = pr * (dp[4 * c + j] - d4[j]);
           }
+          const float pr = __builtin_amdgcn_exp2f(s2);
+          sa[4 * c + j] = DROP ? pr * keep4[j] : pr;     // dV takes the dropped probabilities
+          dp[4 * c + j] = pr * (dp[4 * c + j] - d4[j]);
         }
       }
 #pragma unroll
@@ -459,7 +468,12 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(A
     }  // wave_active
     if (more) lstore(nxt);
     __syncthreads();
-  }
+  };
+  // causal launches: the first tiles (queries up to the block's last key) straddle the diagonal, the rest lie below it
+  int n_diag_end = qt0;
+  if (p.causal) { n_diag_end = (bx * 128 + 127) / 64 + 1; if (n_diag_end > nqt) n_diag_end = nqt; }
+  for (int qt = qt0; qt < n_diag_end; ++qt) tile_body(qt, std::true_type{});
+  for (int qt = n_diag_end; qt < nqt; ++qt) tile_body(qt, std::false_type{});
 
   if (kok) {
     bf16_t* krow = p.dK + (size_t)(b * p.Sk + kcol) * p.lddk + head * D;
