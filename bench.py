@@ -201,8 +201,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=4, help="CPU-baseline batch (SURVEY.md §8d: 4)")
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-baseline steps after one warm-up (SURVEY.md §8d: >= 3)")
-    ap.add_argument("--graph", action="store_true", help="replay the step as one hipGraph (single GPU, SGD); one captured stream, so "
-                    "slower than eager (795 vs 862 img/s): the step is GPU-bound and eager overlaps the text tower on a side stream")
+    ap.add_argument("--graph", action="store_true", help="replay the step as one hipGraph (single GPU, SGD, no dropout): the text-tower fork / join and the "
+                    "tower-wide weight-gradient grid are captured too (LC2IS_GRAPH_OVERLAP=0: one captured stream)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI) | gloo (wiring tests on one GPU)")
     args = ap.parse_args()
 

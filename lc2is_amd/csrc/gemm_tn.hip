@@ -773,22 +773,31 @@ extern "C" int lc2is_gemm_tn_grouped(const lc2is_tn_problem* problems, int n, vo
   if (need && (!workspace || workspace_bytes < need)) return LC2IS_ERR_WORKSPACE;
   // Host image of the table: a ring of PINNED slots, each guarded by an event recorded behind its upload, so a slot is
   // never rewritten while an asynchronous H2D copy may still be reading it (whatever the runtime does with pageable memory).
+  // Under stream capture the upload becomes a memcpy node that re-reads its host source at EVERY replay, so a captured
+  // call gets a pinned image of its own that is never reused (a few KB per captured launch, kept for the process lifetime).
   struct TblSlot { TnGroupTbl* host; hipEvent_t done; bool in_flight; };
   static thread_local TblSlot ring[4] = {};
   static thread_local unsigned ring_pos = 0;
   static thread_local TnGroupTbl small_tbl;     // <= TG_MAX problems travel as kernel arguments: plain host memory
   TblSlot* slot = nullptr;
+  TnGroupTbl* captured_tbl = nullptr;
   if (tbl) {
-    slot = &ring[ring_pos++ & 3];
-    if (!slot->host) {
-      if (hipHostMalloc((void**)&slot->host, sizeof(TnGroupTbl), hipHostMallocDefault) != hipSuccess ||
-          hipEventCreateWithFlags(&slot->done, hipEventDisableTiming) != hipSuccess)
-        return LC2IS_ERR_LAUNCH;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess) return LC2IS_ERR_LAUNCH;
+    if (cap != hipStreamCaptureStatusNone) {
+      if (hipHostMalloc((void**)&captured_tbl, sizeof(TnGroupTbl), hipHostMallocDefault) != hipSuccess) return LC2IS_ERR_LAUNCH;
+    } else {
+      slot = &ring[ring_pos++ & 3];
+      if (!slot->host) {
+        if (hipHostMalloc((void**)&slot->host, sizeof(TnGroupTbl), hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&slot->done, hipEventDisableTiming) != hipSuccess)
+          return LC2IS_ERR_LAUNCH;
+      }
+      if (slot->in_flight && hipEventSynchronize(slot->done) != hipSuccess) return LC2IS_ERR_LAUNCH;
+      slot->in_flight = false;
     }
-    if (slot->in_flight && hipEventSynchronize(slot->done) != hipSuccess) return LC2IS_ERR_LAUNCH;
-    slot->in_flight = false;
   }
-  TnGroupTbl& t = tbl ? *slot->host : small_tbl;
+  TnGroupTbl& t = captured_tbl ? *captured_tbl : (tbl ? *slot->host : small_tbl);
   t.n = n;
   float* ws = (float*)((char*)workspace + (tbl ? TG_TBL_BYTES : 0));
   int blk = 0, red = 0;
@@ -840,12 +849,11 @@ extern "C" int lc2is_gemm_tn_grouped(const lc2is_tn_problem* problems, int n, vo
     attr_set = true;
   }
   if (tbl) {
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;   // a captured copy would re-read this host ring at every replay
-    if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return LC2IS_ERR_UNSUPPORTED;
-    if (hipMemcpyAsync(workspace, &t, sizeof(TnGroupTbl), hipMemcpyHostToDevice, stream) != hipSuccess ||
-        hipEventRecord(slot->done, stream) != hipSuccess)
-      return LC2IS_ERR_LAUNCH;
-    slot->in_flight = true;
+    if (hipMemcpyAsync(workspace, &t, sizeof(TnGroupTbl), hipMemcpyHostToDevice, stream) != hipSuccess) return LC2IS_ERR_LAUNCH;
+    if (slot) {
+      if (hipEventRecord(slot->done, stream) != hipSuccess) return LC2IS_ERR_LAUNCH;
+      slot->in_flight = true;
+    }
     const TnGroupTbl* dt = (const TnGroupTbl*)workspace;
     if (pl.small)
       hipLaunchKernelGGL(gemm_tn_grouped_small_tbl_kernel, dim3(blk), dim3(256), 2 * TN_STAGE, stream, dt);

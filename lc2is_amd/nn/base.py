@@ -229,7 +229,7 @@ class WgradBatch:
 
     def flush(self):
         items, self.items = self.items, []
-        gmax = ops.GROUP_MAX_CAPTURABLE if torch.cuda.is_current_stream_capturing() else ops.GROUP_MAX
+        gmax = ops.GROUP_MAX
         for i in range(0, len(items), gmax):
             chunk = items[i:i + gmax]
             if len(chunk) == 1:

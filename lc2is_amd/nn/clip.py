@@ -192,9 +192,7 @@ def _stack_bwd(g32, g16, stack: _Stack, sh, saved, a: ClipArch, B: int, S: int, 
     # Under data parallelism three layers share a launch (324 tiles: 1 full round + a finely split tail round, planner cost
     # 242 steps per layer against 287 for one layer and 225 for the tower) and report to the reducer together: its buckets
     # are >= 48 MB (two layers) anyway, so the all-reduce of a group still starts under the backward of the next group.
-    if torch.cuda.is_current_stream_capturing():
-        default_pair = 1
-    elif on_layer_done is not None:
+    if on_layer_done is not None:
         default_pair = min(3, len(stack.layers))
     else:
         default_pair = len(stack.layers)

@@ -48,7 +48,7 @@ def _scores_bwd(ds32, sv):
     dvn = dvn.view(B * P, C)
     vn16 = sv["vn16"]
     probs = [(ds16[b * P:(b + 1) * P], vn16[b * P:(b + 1) * P], dtn[b], None, False) for b in range(B)]
-    gmax = ops.GROUP_MAX_CAPTURABLE if torch.cuda.is_current_stream_capturing() else ops.GROUP_MAX
+    gmax = ops.GROUP_MAX
     for i in range(0, B, gmax):                                                    # the B weight-gradient-shaped products: one grid
         ops.gemm_tn_grouped(probs[i:i + gmax])
     dv = ops.l2norm_bwd(dvn, sv["v32"], sv["vinv"])

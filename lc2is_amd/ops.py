@@ -230,7 +230,6 @@ class TnProblem(C.Structure):
 
 
 GROUP_MAX = 128        # LC2IS_TN_GROUP_MAX
-GROUP_MAX_CAPTURABLE = 16   # above this the call uploads its descriptor table (H2D copy): not hipGraph-capturable
 
 
 # rows (tokens) from which a weight gradient joins a grouped launch: the text tower (151 prompts x 16 tokens = 2416 rows, 72

@@ -84,8 +84,10 @@ class TrainStep:
         Single-process only (the RCCL reduction is not captured)."""
         if self.reducer is not None:
             raise RuntimeError("TrainStep.capture: graph capture is only wired for single-GPU steps")
-        if hasattr(self.model, "overlap_text") and os.environ.get("LC2IS_GRAPH_OVERLAP", "0") != "1":
-            self.model.overlap_text = False   # one captured stream (LC2IS_GRAPH_OVERLAP=1: capture the text-tower fork / join too)
+        if hasattr(self.model, "overlap_text") and os.environ.get("LC2IS_GRAPH_OVERLAP", "1") == "0":
+            self.model.overlap_text = False   # LC2IS_GRAPH_OVERLAP=0: one captured stream (default: the text-tower fork / join is captured too)
+        from .nn.base import DropoutRng
+        DropoutRng.last.clear()
         static_in = {k: v.clone() for k, v in inputs.items()}
         static_lb = labels.clone()
         side = torch.cuda.Stream()
@@ -95,6 +97,9 @@ class TrainStep:
                 self.step(static_in, static_lb)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if DropoutRng.last:   # dropout seeds are kernel ARGUMENTS drawn on the host: a replay would repeat one step's masks
+            raise RuntimeError("TrainStep.capture: the model has active dropout / drop-path sites "
+                               f"({len(DropoutRng.last)}); their per-step seeds cannot be captured — train eagerly or set the rates to 0")
         graph = torch.cuda.CUDAGraph()
         t_before = self.t
         with torch.cuda.graph(graph, stream=side):
