@@ -64,3 +64,40 @@ def test_capture_refuses_active_dropout(dev):
     ts = TrainStep(m, optimizer="sgd", lr=0.05)
     with pytest.raises(RuntimeError, match="dropout"):
         ts.capture(*_batch(dev, 0))
+
+
+def test_grouped_table_launch_survives_capture(dev):
+    """> 16 problems: the descriptor table is uploaded by a captured memcpy node that re-reads its host image at every replay;
+    the image belongs to the captured call alone, so eager launches between replays (which cycle the pinned ring) cannot
+    change what the graph uploads."""
+    from lc2is_amd import ops
+    torch.manual_seed(3)
+    n, M, N, K = 20, 512, 64, 128
+    dys = [torch.randn(M, N, device=dev).bfloat16() for _ in range(n)]
+    xs = [torch.randn(M, K, device=dev).bfloat16() for _ in range(n)]
+    dws = [torch.zeros(N, K, device=dev) for _ in range(n)]
+    dbs = [torch.zeros(N, device=dev) for _ in range(n)]
+    probs = [(dy, x, dw, db, False) for dy, x, dw, db in zip(dys, xs, dws, dbs)]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.gemm_tn_grouped(probs)      # warm-up: workspace, attributes
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        ops.gemm_tn_grouped(probs)
+    # eager table launches on OTHER buffers cycle all four ring slots
+    other = [(torch.randn(M, N, device=dev).bfloat16(), torch.randn(M, K, device=dev).bfloat16(),
+              torch.zeros(N, K, device=dev), None, False) for _ in range(n)]
+    for _ in range(5):
+        ops.gemm_tn_grouped(other)
+    for rep in range(2):
+        for dy, x in zip(dys, xs):
+            dy.copy_(torch.randn(M, N, device=dev)); x.copy_(torch.randn(M, K, device=dev))
+        g.replay()
+        torch.cuda.synchronize()
+        for dy, x, dw, db in zip(dys, xs, dws, dbs):
+            ref = dy.float().t() @ x.float()
+            assert ((dw - ref).norm() / ref.norm()).item() < 2e-3
+            assert ((db - dy.float().sum(0)).norm() / dy.float().sum(0).norm()).item() < 2e-3
