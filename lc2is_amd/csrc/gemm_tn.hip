@@ -785,7 +785,11 @@ extern "C" int lc2is_gemm_tn_grouped(const lc2is_tn_problem* problems, int n, vo
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cap) != hipSuccess) return LC2IS_ERR_LAUNCH;
     if (cap != hipStreamCaptureStatusNone) {
-      if (hipHostMalloc((void**)&captured_tbl, sizeof(TnGroupTbl), hipHostMallocDefault) != hipSuccess) return LC2IS_ERR_LAUNCH;
+      // (an allocation is an "unsafe" call under the default global capture mode: relax this thread's mode around it)
+      hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+      if (hipThreadExchangeStreamCaptureMode(&mode) != hipSuccess) return LC2IS_ERR_LAUNCH;
+      const hipError_t e = hipHostMalloc((void**)&captured_tbl, sizeof(TnGroupTbl), hipHostMallocDefault);
+      if (hipThreadExchangeStreamCaptureMode(&mode) != hipSuccess || e != hipSuccess) return LC2IS_ERR_LAUNCH;
     } else {
       slot = &ring[ring_pos++ & 3];
       if (!slot->host) {

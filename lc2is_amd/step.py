@@ -80,7 +80,9 @@ class TrainStep:
     def capture(self, inputs: dict, labels: torch.Tensor, warmup: int = 2):
         """Capture one full step (shadow refresh -> forward -> CE -> backward -> optimizer) into a hipGraph over
         static copies of the batch; returns ``replay(inputs, labels) -> loss`` which copies the new batch into the
-        static buffers and launches the graph (one host call per step instead of ~800 kernel launches).
+        static buffers and launches the graph (one host call per step instead of ~800 kernel launches).  ``warmup`` REAL
+        steps on ``inputs`` run before the capture (lazy initialisation must not happen inside it); the captured step itself
+        is only recorded.
         Single-process only (the RCCL reduction is not captured)."""
         if self.reducer is not None:
             raise RuntimeError("TrainStep.capture: graph capture is only wired for single-GPU steps")
@@ -106,7 +108,7 @@ class TrainStep:
             static_loss = self.step(static_in, static_lb)
         if self.kind == "adamw":
             raise RuntimeError("TrainStep.capture: AdamW bias correction is step-dependent; capture supports SGD")
-        self.t = t_before + 1
+        self.t = t_before   # capture records the step; nothing ran
 
         def replay(new_inputs: dict, new_labels: torch.Tensor) -> torch.Tensor:
             for k, v in new_inputs.items():

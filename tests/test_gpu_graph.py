@@ -40,8 +40,8 @@ def test_graph_replay_matches_eager(dev):
     m_e, m_g = _model(dev), _model(dev)
     m_g.load_state_dict(m_e.state_dict())
     ts_e, ts_g = TrainStep(m_e, optimizer="sgd", lr=0.05), TrainStep(m_g, optimizer="sgd", lr=0.05)
-    # capture() itself runs 2 warm-up steps + the captured one on the first batch
-    for _ in range(3):
+    # capture() runs 2 real warm-up steps on the first batch, then records (does not run) the captured one
+    for _ in range(2):
         ts_e.step(*batches[0])
     run = ts_g.capture(*batches[0])
     torch.cuda.synchronize()
