@@ -126,6 +126,24 @@ int lc2is_layernorm_bwd(const void* dy_bf16, int lddy, const float* dy_f32, int 
                         float* dgamma, float* dbeta, int accumulate, int M, int C, void* workspace,
                         size_t workspace_bytes, lc2is_stream_t stream);
 
+/* Deferred parameter gradients: a lc2is_layernorm_bwd call with dgamma == dbeta == NULL leaves its per-block partial
+ * sums in `workspace` — lc2is_layernorm_bwd_partials(M, C) rows of [dgamma partial (C) | dbeta partial (C)] — and
+ * lc2is_ln_partials_reduce sums the partials of up to LC2IS_LN_PARTIALS_MAX such calls in ONE launch (fixed-order sums:
+ * bit-identical to the per-call second launch).  Items must not share an output vector (-> LC2IS_ERR_UNSUPPORTED).
+ * replaces: the weight.grad / bias.grad accumulation of every nn.LayerNorm of a tower's backward (autograd of
+ *   hf:CLIPEncoderLayer.forward:362-383; 50 latency-bound 13-us launches per train step become two). */
+#define LC2IS_LN_PARTIALS_MAX 64
+typedef struct {
+  const float* partials; /* the workspace of the lc2is_layernorm_bwd call */
+  float* dgamma;         /* [C] or NULL */
+  float* dbeta;          /* [C] or NULL */
+  int nparts;            /* lc2is_layernorm_bwd_partials(M, C) of that call */
+  int C;
+  int accumulate;        /* 0: overwrite, 1: add to the vectors */
+} lc2is_ln_partials;
+int lc2is_layernorm_bwd_partials(int M, int C);
+int lc2is_ln_partials_reduce(const lc2is_ln_partials* items, int n, lc2is_stream_t stream);
+
 /* ---- attention -----------------------------------------------------------------------------------
  * O[b,s,h,:] = softmax_k( scale * Q[b,s,h,:]·K[b,k,h,:] + kbias[b,k] (+ causal) ) · V[b,k,h,:]
  * Q/K/V/O are token-major 2-D views: row (b*S + s), head h in columns [h*D,(h+1)*D), row stride ld*

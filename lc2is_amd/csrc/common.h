@@ -115,16 +115,12 @@ namespace {
 // (8 float4 groups) x 128 row lanes, so a thread has at most nparts/128 independent 16-byte loads in flight (8 for the
 // 1024 LayerNorm partials), then a fixed-order 128 -> 32 -> 1 LDS tree (reproducible).  grid.x = ceil(W / 32); grid.y
 // selects an (ws, out) pair offset by (y*ws_off_y, out1 if y==1).
-__global__ __launch_bounds__(1024) void partials_reduce_kernel(const float* __restrict__ ws, int nparts,
-                                                                size_t stride, size_t ws_off_y, int W, float* out0,
-                                                                float* out1, int accumulate) {
+__device__ __forceinline__ void partials_reduce_body(const float* __restrict__ w, int nparts, size_t stride, int W,
+                                                     float* out, int accumulate, int bx) {
   __shared__ f32x4_t red[128][8];
   __shared__ f32x4_t red2[32][8];
   const int cx = threadIdx.x & 7, ry = threadIdx.x >> 3;
-  const int c = blockIdx.x * 32 + cx * 4;
-  float* out = blockIdx.y ? out1 : out0;
-  if (!out) return;
-  const float* w = ws + blockIdx.y * ws_off_y;
+  const int c = bx * 32 + cx * 4;
   f32x4_t s = {0.f, 0.f, 0.f, 0.f};
   if (c < W) {
 #pragma unroll 8
@@ -145,6 +141,14 @@ __global__ __launch_bounds__(1024) void partials_reduce_kernel(const float* __re
     for (int e = 0; e < 4; ++e)
       if (c + e < W) out[c + e] = accumulate ? out[c + e] + t[e] : t[e];
   }
+}
+
+__global__ __launch_bounds__(1024) void partials_reduce_kernel(const float* __restrict__ ws, int nparts,
+                                                                size_t stride, size_t ws_off_y, int W, float* out0,
+                                                                float* out1, int accumulate) {
+  float* out = blockIdx.y ? out1 : out0;
+  if (!out) return;
+  partials_reduce_body(ws + blockIdx.y * ws_off_y, nparts, stride, W, out, accumulate, blockIdx.x);
 }
 }  // namespace
 

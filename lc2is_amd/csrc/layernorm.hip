@@ -252,3 +252,48 @@ extern "C" int lc2is_layernorm_bwd(const void* dy_bf16, int lddy, const float* d
   }
   return rc;
 }
+
+// The per-block partial sums a lc2is_layernorm_bwd call with dgamma == dbeta == NULL leaves in its workspace:
+// `lc2is_layernorm_bwd_partials(M, C)` rows of [dgamma partial (C) | dbeta partial (C)].
+extern "C" int lc2is_layernorm_bwd_partials(int M, int C) {
+  if (M <= 0 || C <= 0 || C % 4 || C > LN_MAXV * 256) return 0;
+  return ln_bwd_blocks(M, C);
+}
+
+namespace {
+struct LnPartialsGroup {
+  lc2is_ln_partials item[LC2IS_LN_PARTIALS_MAX];
+};
+__global__ __launch_bounds__(1024) void ln_partials_reduce_grouped_kernel(LnPartialsGroup g) {
+  const lc2is_ln_partials& it = g.item[blockIdx.z];
+  if ((int)blockIdx.x * 32 >= it.C) return;
+  float* out = blockIdx.y ? it.dbeta : it.dgamma;
+  if (!out) return;
+  partials_reduce_body(it.partials + (size_t)blockIdx.y * it.C, it.nparts, (size_t)2 * it.C, it.C, out, it.accumulate,
+                       blockIdx.x);
+}
+}  // namespace
+
+// The dgamma / dbeta reductions of up to LC2IS_LN_PARTIALS_MAX LayerNorm backward calls in ONE launch (descriptors travel
+// as kernel arguments; fixed-order sums, so the result is the one the per-call reduce gives).  Two items must not share
+// an output vector.
+extern "C" int lc2is_ln_partials_reduce(const lc2is_ln_partials* items, int n, lc2is_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!items) return LC2IS_ERR_NULL;
+  if (n <= 0 || n > LC2IS_LN_PARTIALS_MAX) return LC2IS_ERR_SHAPE;
+  LnPartialsGroup g{};
+  int cmax = 0;
+  for (int i = 0; i < n; ++i) {
+    const lc2is_ln_partials& it = items[i];
+    if (!it.partials || (!it.dgamma && !it.dbeta)) return LC2IS_ERR_NULL;
+    if (it.nparts <= 0 || it.C <= 0 || it.C % 4) return LC2IS_ERR_SHAPE;
+    for (int j = 0; j < i; ++j)
+      if ((it.dgamma && (it.dgamma == items[j].dgamma || it.dgamma == items[j].dbeta)) ||
+          (it.dbeta && (it.dbeta == items[j].dgamma || it.dbeta == items[j].dbeta)))
+        return LC2IS_ERR_UNSUPPORTED;
+    g.item[i] = it;
+    cmax = it.C > cmax ? it.C : cmax;
+  }
+  hipLaunchKernelGGL(ln_partials_reduce_grouped_kernel, dim3((cmax + 31) / 32, 2, n), dim3(1024), 0, stream, g);
+  return lc2is_check_launch();
+}

@@ -218,6 +218,7 @@ class WgradBatch:
     def __enter__(self):
         if self.enabled:
             self._prev, WgradBatch._active = WgradBatch._active, self
+            self._prev_ln = ops.ln_defer_begin()   # the LayerNorm dgamma / dbeta reductions of the block leave together too
         return self
 
     def __exit__(self, exc_type, *exc):
@@ -225,9 +226,13 @@ class WgradBatch:
             WgradBatch._active = self._prev
             if exc_type is None:
                 self.flush()
+                ops.ln_defer_end(self._prev_ln)
+            else:
+                ops._ln_defer = self._prev_ln
         return False
 
     def flush(self):
+        ops.ln_defer_flush()
         items, self.items = self.items, []
         gmax = ops.GROUP_MAX
         for i in range(0, len(items), gmax):

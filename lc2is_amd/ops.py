@@ -27,6 +27,8 @@ _ARGTYPES = {
     "lc2is_colsum_workspace_bytes": [_I, _I],
     "lc2is_colsum_bf16": [_P, _I, _P, _I, _I, _I, _P, _Z, _P],
     "lc2is_layernorm_fwd": [_P, _I, _P, _P, _P, _I, _P, _I, _P, _P, _I, _I, _F, _P],
+    "lc2is_layernorm_bwd_partials": [_I, _I],
+    "lc2is_ln_partials_reduce": [_P, _I, _P],
     "lc2is_layernorm_bwd_workspace_bytes": [_I, _I],
     "lc2is_layernorm_bwd": [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I,
                             _P, _Z, _P],
@@ -314,13 +316,71 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: 
             if dbeta is None:
                 dbeta = torch.empty((Cc,), dtype=torch.float32, device=dev)
     nbytes = _fn("lc2is_layernorm_bwd_workspace_bytes")(M, Cc)
-    ws = workspace(nbytes, dev, "ln_bwd")
+    defer = _ln_defer if (need_param_grads and (dgamma is not None or dbeta is not None)) else None
+    if defer is not None:
+        # parameter gradients deferred (ln_defer_begin/flush): the partial sums stay in a buffer of their own until the
+        # grouped reduce at the end of the layer group
+        ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dev)
+        defer.append((ws, _fn("lc2is_layernorm_bwd_partials")(M, Cc), Cc, dgamma, dbeta, bool(accumulate)))
+        pg, pb = None, None
+    else:
+        ws = workspace(nbytes, dev, "ln_bwd")
+        pg, pb = dgamma, dbeta
     rc = _fn("lc2is_layernorm_bwd")(_ptr(dyb), _ld(dyb), _ptr(dyf), _ld(dyf), _ptr(x), _ld(x), _ptr(gamma),
                                     _ptr(mean), _ptr(rstd), _ptr(dres), _ld(dres), _ptr(dxf), _ld(dxf),
-                                    _ptr(dxb), _ld(dxb), _ptr(dgamma), _ptr(dbeta), int(accumulate), M, Cc,
+                                    _ptr(dxb), _ld(dxb), _ptr(pg), _ptr(pb), int(accumulate), M, Cc,
                                     _ptr(ws), ws.numel(), _stream())
     _lib.check(rc, f"layernorm_bwd M={M} C={Cc}")
     return dxf, dxb, dgamma, dbeta
+
+
+class LnPartials(C.Structure):
+    _fields_ = [("partials", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("nparts", C.c_int),
+                ("C", C.c_int), ("accumulate", C.c_int)]
+
+
+LN_PARTIALS_MAX = 64   # LC2IS_LN_PARTIALS_MAX
+_ln_defer = None       # list of deferred (ws, nparts, C, dgamma, dbeta, accumulate) while a deferral scope is open
+
+
+def ln_defer_begin():
+    """Open a deferral scope: layernorm_bwd calls that are handed dgamma / dbeta buffers keep their partial sums and the
+    reductions leave together at ln_defer_flush (nn.base.WgradBatch opens / flushes one with the weight gradients).
+    Returns the previous scope (pass it to ln_defer_end)."""
+    global _ln_defer
+    prev, _ln_defer = _ln_defer, []
+    return prev
+
+
+def ln_defer_flush():
+    """One grouped launch per <= LN_PARTIALS_MAX deferred calls (two calls that write the same vector are never put in
+    the same launch: the second waits for the next one)."""
+    global _ln_defer
+    items = _ln_defer
+    if not items:
+        return
+    _ln_defer = []
+    while items:
+        chunk, rest, seen = [], [], set()
+        for it in items:
+            outs = {t.data_ptr() for t in (it[3], it[4]) if t is not None}
+            if len(chunk) < LN_PARTIALS_MAX and not (outs & seen) and not rest:
+                chunk.append(it); seen |= outs
+            else:
+                rest.append(it)
+        arr = (LnPartials * len(chunk))()
+        for i, (ws, nparts, Cc, dg, db, acc) in enumerate(chunk):
+            _chk(dg, torch.float32, "dgamma", 1); _chk(db, torch.float32, "dbeta", 1)
+            arr[i] = LnPartials(_ptr(ws), _ptr(dg), _ptr(db), nparts, Cc, int(acc))
+        rc = _fn("lc2is_ln_partials_reduce")(arr, len(chunk), _stream())
+        _lib.check(rc, f"ln_partials_reduce n={len(chunk)}")
+        items = rest
+
+
+def ln_defer_end(prev):
+    global _ln_defer
+    ln_defer_flush()
+    _ln_defer = prev
 
 
 def attention_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, H: int, Sq: int, Sk: int, D: int,

@@ -230,6 +230,46 @@ def test_layernorm_fwd_bwd(dev, M, C):
     assert _rel(dxf2, xd.grad) < 1e-5
 
 
+def test_layernorm_bwd_deferred_param_grads_are_bitwise_equal(dev):
+    """The dgamma / dbeta reductions of several LayerNorm backward calls in one grouped launch (ops.ln_defer_begin/flush,
+    opened by nn.base.WgradBatch): same fixed-order sums as the per-call second launch, incl. accumulate and a vector that
+    two calls of the scope write (the second is reduced in a later launch)."""
+    torch.manual_seed(5)
+    shapes = [(4100, 768), (333, 768), (2050, 512), (77, 64)]
+    cases = []
+    for M, C in shapes:
+        x = torch.randn(M, C, device=dev)
+        gamma = torch.randn(C, device=dev)
+        _, _, mean, rstd = ops.layernorm_fwd(x, gamma, torch.zeros(C, device=dev))
+        cases.append((torch.randn(M, C, device=dev).bfloat16(), x, gamma, mean, rstd))
+    base_g = [torch.randn(C, device=dev) for _, C in shapes]
+    base_b = [torch.randn(C, device=dev) for _, C in shapes]
+
+    def run(deferred):
+        dgs, dbs = [t.clone() for t in base_g], [t.clone() for t in base_b]
+        prev = ops.ln_defer_begin() if deferred else None
+        outs = []
+        for i, (dy, x, gamma, mean, rstd) in enumerate(cases):
+            acc = i % 2 == 1
+            outs.append(ops.layernorm_bwd(dy, x, gamma, mean, rstd, dgamma=dgs[i], dbeta=dbs[i], accumulate=acc)[0])
+        # a second call into the vectors of case 0 (a module used twice inside one scope)
+        dy, x, gamma, mean, rstd = cases[0]
+        ops.layernorm_bwd(dy, x, gamma, mean, rstd, dgamma=dgs[0], dbeta=dbs[0], accumulate=True)
+        if deferred:
+            assert len(ops._ln_defer) == len(cases) + 1
+            ops.ln_defer_end(prev)
+            assert ops._ln_defer is prev
+        torch.cuda.synchronize()
+        return dgs, dbs, outs
+
+    g0, b0, o0 = run(False)
+    g1, b1, o1 = run(True)
+    for a, b in zip(g0 + b0 + o0, g1 + b1 + o1):
+        assert torch.equal(a, b)
+    ref = (cases[0][0].float() * ((cases[0][1] - cases[0][3][:, None]) * cases[0][4][:, None])).sum(0) * 2
+    assert ((g1[0] - ref).norm() / ref.norm()).item() < 1e-3
+
+
 def test_gemm_nt_pingpong_is_bitwise_equal_to_simple_pipeline(dev):
     """The ping-pong kernel (hand-placed waits, staggered wave groups) accumulates in the same order as the
     simple LDS-DMA kernel: any race in its schedule shows up as a bit difference.  Several shapes x repeats."""
