@@ -340,6 +340,7 @@ class LnPartials(C.Structure):
 
 
 LN_PARTIALS_MAX = 64   # LC2IS_LN_PARTIALS_MAX
+_LN_DEFER = os.environ.get("LC2IS_LN_DEFER", "1") != "0"   # A/B switch: 0 = every layernorm_bwd reduces its own partials
 _ln_defer = None       # list of deferred (ws, nparts, C, dgamma, dbeta, accumulate) while a deferral scope is open
 
 
@@ -348,7 +349,7 @@ def ln_defer_begin():
     reductions leave together at ln_defer_flush (nn.base.WgradBatch opens / flushes one with the weight gradients).
     Returns the previous scope (pass it to ln_defer_end)."""
     global _ln_defer
-    prev, _ln_defer = _ln_defer, []
+    prev, _ln_defer = _ln_defer, ([] if _LN_DEFER else None)
     return prev
 
 

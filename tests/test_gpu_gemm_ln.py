@@ -234,6 +234,7 @@ def test_layernorm_bwd_deferred_param_grads_are_bitwise_equal(dev):
     """The dgamma / dbeta reductions of several LayerNorm backward calls in one grouped launch (ops.ln_defer_begin/flush,
     opened by nn.base.WgradBatch): same fixed-order sums as the per-call second launch, incl. accumulate and a vector that
     two calls of the scope write (the second is reduced in a later launch)."""
+    from lc2is_amd import ops
     torch.manual_seed(5)
     shapes = [(4100, 768), (333, 768), (2050, 512), (77, 64)]
     cases = []
