@@ -630,7 +630,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_dma_kernel(Gemm
 // LDS patches live in the other stage), the epilogue's non-temporal stores drain under the next tile's MFMA loop, and there
 // is no per-tile block launch.
 template <int ACT>
-__global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtArgs p, int ntiles) {
+__global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtArgs p, int ntiles, int stagger) {
   constexpr int BM = 256, BN = 256, WAVES_N = 4, BK = 64;
   constexpr int WM = 128, WN = 64, TM = 8, TN = 4;
   constexpr int A_PIECES = 4, W_PIECES = 4;
@@ -659,6 +659,10 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtArgs p, int 
 
   int t = blockIdx.x;
   if (t >= ntiles) return;
+  if (stagger > 0) {   // experiment: start the blocks of an XCD in 8 phases so that their epilogues do not coincide
+    const long long wait = (long long)((blockIdx.x >> 3) & 7) * stagger, t0 = wall_clock64();
+    while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(64);
+  }
   first_stage(t, lane0);
   for (;;) {
     // every per-lane constant of the main loop is rebuilt per output tile from a laundered lane id, so nothing but the
@@ -1084,7 +1088,8 @@ int launch_persist_act(const GemmNtArgs& a, hipStream_t stream) {
   }
   const int ntiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
   const int grid = ntiles < 256 ? ntiles : 256;
-  hipLaunchKernelGGL(gemm_nt_persist_kernel<ACT>, dim3(grid), dim3(512), LDS, stream, a, ntiles);
+  static const int stagger = getenv("LC2IS_GEMM_STAGGER") ? atoi(getenv("LC2IS_GEMM_STAGGER")) : 0;   // 10-ns ticks per phase
+  hipLaunchKernelGGL(gemm_nt_persist_kernel<ACT>, dim3(grid), dim3(512), LDS, stream, a, ntiles, stagger);
   return lc2is_check_launch();
 }
 
