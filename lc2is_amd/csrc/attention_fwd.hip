@@ -20,6 +20,7 @@
 #include "common.h"
 #include "lc2is_hip.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -82,6 +83,33 @@ __device__ __forceinline__ bf16x8_t tr_frag2(const char* base, int addr_lo, int 
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// a ring-stage byte offset that is either a compile-time constant (the unrolled main loop: it folds into the LDS instructions'
+// offset fields and into m0) or a run-time value (the rolled loop of the leftover / masked tiles)
+template <int V> using CtOff = std::integral_constant<int, V>;
+struct RtOff {
+  int v;
+  __device__ constexpr operator int() const { return v; }
+};
+
+// LDS accesses by 32-bit LDS address (base register + immediate): the address of `extern __shared__` memory is only fixed
+// when the module's static LDS is laid out, after instruction selection, so `smem + lane_offset + constant` costs a
+// `v_add_u32 v, 0, v` per access; a lane's fragment bases are formed ONCE as opaque LDS addresses instead
+__device__ __forceinline__ bf16x8_t lds_read_b128(unsigned addr) {
+  return *(const __attribute__((address_space(3))) bf16x8_t*)(size_t)addr;
+}
+__device__ __forceinline__ bf16x8_t tr_frag2a(unsigned addr_lo, unsigned addr_hi) {
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(size_t)addr_lo);
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(size_t)addr_hi);
+  s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+__device__ __forceinline__ float max2f(float a, float b) {
+  float d;
+  asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
 __device__ __forceinline__ float max3f(float a, float b, float c) {
   float d;   // one VALU op for two comparisons (hipcc otherwise canonicalises the MFMA outputs before every fmaxf)
   asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
@@ -154,14 +182,13 @@ __global__ __launch_bounds__(256, (D == 64) ? 3 : 2) void attn_fwd_kernel(AttnFw
     k_goff[j] = ch < Cfg::CH ? ((b * p.Sk + row) * p.ldk + head * D + ch * 8) * 2 : -1;
     v_goff[j] = ch < Cfg::CH ? ((b * p.Sk + row) * p.ldv + head * D + ch * 8) * 2 : -1;
   }
-  auto request = [&](int kt) {   // tile kt -> ring slot kt % NSTAGE
-    attn_dma_tile<D>(p.K, kbytes, p.V, vbytes, smem + (kt % NSTAGE) * Cfg::STAGE, wid, k_goff, v_goff, kt * 64 * p.ldk * 2,
-                     kt * 64 * p.ldv * 2);
+  auto request = [&](int kt, int so) __attribute__((always_inline)) {   // tile kt -> the ring slot at byte offset so = (kt % NSTAGE) * STAGE
+    attn_dma_tile<D>(p.K, kbytes, p.V, vbytes, smem + so, wid, k_goff, v_goff, kt * 64 * p.ldk * 2, kt * 64 * p.ldv * 2);
   };
   // the first PD tiles are on their way before anything else happens (their latency overlaps the Q loads below)
 #pragma unroll
   for (int i = 0; i < PD; ++i)
-    if (i < nkt) request(i);
+    if (i < nkt) request(i, i * Cfg::STAGE);
 
   // Q fragments (B operand of S^T = K·Q^T): lane holds Q[qrow][16s + 8hh .. +7]
   bf16x8_t qf[NKS];
@@ -176,14 +203,19 @@ __global__ __launch_bounds__(256, (D == 64) ? 3 : 2) void attn_fwd_kernel(AttnFw
 
   // fragment addresses in a stage (the swizzle only looks at row bits 0..3: 16- / 32-row steps are immediates on these bases)
   const int q4 = (lane >> 2) & 3, p4 = lane & 3, cg = (lane >> 4) & 1;
-  int k_row[NKS], v_lo[NDT], v_hi[NDT];
+  const unsigned smem_a = (unsigned)(size_t)LDS_PTR(smem);
+  unsigned k_row[NKS], v_lo[NDT], v_hi[NDT];   // LDS addresses in stage 0
 #pragma unroll
-  for (int s = 0; s < NKS; ++s) k_row[s] = Cfg::off(l31, 2 * s + hh);          // + 32t*PITCH
+  for (int s = 0; s < NKS; ++s) {
+    k_row[s] = smem_a + Cfg::off(l31, 2 * s + hh);          // + 32t*PITCH
+    asm volatile("" : "+v"(k_row[s]));
+  }
 #pragma unroll
   for (int d = 0; d < NDT; ++d) {
     const int e = 32 * d + 16 * cg + 4 * p4;
-    v_lo[d] = Cfg::TILE + Cfg::off(4 * hh + q4, e >> 3) + (e & 7) * 2;        // + (32t + 16 s2)*PITCH
-    v_hi[d] = Cfg::TILE + Cfg::off(4 * hh + q4 + 8, e >> 3) + (e & 7) * 2;
+    v_lo[d] = smem_a + Cfg::TILE + Cfg::off(4 * hh + q4, e >> 3) + (e & 7) * 2;        // + (32t + 16 s2)*PITCH
+    v_hi[d] = smem_a + Cfg::TILE + Cfg::off(4 * hh + q4 + 8, e >> 3) + (e & 7) * 2;
+    asm volatile("" : "+v"(v_lo[d]), "+v"(v_hi[d]));
   }
 
   f32x16_t ot[NDT];
@@ -191,26 +223,28 @@ __global__ __launch_bounds__(256, (D == 64) ? 3 : 2) void attn_fwd_kernel(AttnFw
   for (int d = 0; d < NDT; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) ot[d][r] = 0.f;
-  float lsum = 0.f, m_ref = 0.f;   // lsum: this lane's share of the row sum (its 16 keys per half tile); m_ref: the row's frame
+  f32x2_t lsum2 = {0.f, 0.f};      // this lane's share of the row sum (its 16 keys per half tile), even / odd scores apart (packed adds)
+  float m_ref = 0.f;               // the row's frame
   bool counted = false;            // has the row met an unmasked key (its frame is then a real score's maximum)
 
   // S^T = K · Q^T of one 32-key half tile (raw, unscaled): 4 (D/16) LDS row reads + dependent MFMAs
-  auto issue_s = [&](int so, int t, f32x16_t& st) {
+  auto issue_s = [&](int so, int t, f32x16_t& st) __attribute__((always_inline)) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[r] = 0.f;
 #pragma unroll
     for (int s = 0; s < NKS; ++s) {
-      const bf16x8_t kf = *(const bf16x8_t*)(smem + so + k_row[s] + 32 * t * PITCH);
+      const bf16x8_t kf = lds_read_b128(k_row[s] + (unsigned)(so + 32 * t * PITCH));
       st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st, 0, 0, 0);
     }
   };
   // block 1 of a half step: scale into the row's frame, masks, per-lane maximum, frame check (the only branch)
-  auto frame = [&](f32x16_t& st, int kt, int t) {
+  // (masked_c = false_type: the caller knows the tile has no key tail, no causal edge and no key bias — no mask code at all)
+  auto frame = [&](f32x16_t& st, int kt, int t, auto masked_c) __attribute__((always_inline)) {
     const bool tail = (kt * 64 + 64 > p.Sk);
     const bool diag = p.causal && (kt * 64 + 63 > bx * QB);  // some key may exceed some query
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[r] = __builtin_fmaf(st[r], p.scale_log2, -m_ref);
-    if (tail || diag || p.kbias != nullptr) {   // key tail / key padding / causal edge: -inf (or the additive key bias) per score
+    if (decltype(masked_c)::value && (tail || diag || p.kbias != nullptr)) {   // key tail / key padding / causal edge: -inf (or the additive key bias) per score
       int key0 = kt * 64 + 32 * t + 4 * hh, qr = qrow;
       asm volatile("" : "+v"(key0), "+v"(qr));   // keeps the per-score compares INSIDE this branch (hipcc hoists them otherwise)
 #pragma unroll
@@ -230,7 +264,7 @@ __global__ __launch_bounds__(256, (D == 64) ? 3 : 2) void attn_fwd_kernel(AttnFw
     mb = max3f(mb, st[8], st[9]);
     ma = max3f(ma, st[10], st[11]);
     mb = max3f(mb, st[12], st[13]);
-    const float mx = max3f(ma, mb, fmaxf(st[14], st[15]));
+    const float mx = max2f(max3f(ma, st[14], st[15]), mb);
     if (__any((mx > FRAME_THR) || (!counted && mx > NEG_INF))) {
       // rare: some row outgrew its frame (or met its first key): move those rows to the frame of their new maximum
       const float mxx = fmaxf(mx, __shfl_xor(mx, 32, 64));            // the row's maximum over both lane halves
@@ -241,7 +275,7 @@ __global__ __launch_bounds__(256, (D == 64) ? 3 : 2) void attn_fwd_kernel(AttnFw
       for (int d = 0; d < NDT; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) ot[d][r] *= corr;
-      lsum *= corr;
+      lsum2 *= corr;
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[r] -= delta;
       m_ref += delta;
@@ -249,14 +283,11 @@ __global__ __launch_bounds__(256, (D == 64) ? 3 : 2) void attn_fwd_kernel(AttnFw
     }
   };
   // block 2 of a half step: P = exp2(s - m_ref), row sums, pack, O^T += V^T · P^T   (+ the next half's S^T chain, see the loop)
-  auto finish = [&](f32x16_t& st, int so, int kt, int t) {
-    float ps = 0.f;
+  auto finish = [&](f32x16_t& st, int so, int kt, int t) __attribute__((always_inline)) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      st[r] = __builtin_amdgcn_exp2f(st[r]);
-      ps += st[r];
-    }
-    lsum += ps;
+    for (int r = 0; r < 16; ++r) st[r] = __builtin_amdgcn_exp2f(st[r]);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) lsum2 += f32x2_t{st[2 * r], st[2 * r + 1]};   // v_pk_add_f32
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
       bf16x8_t pf;
@@ -273,63 +304,89 @@ __global__ __launch_bounds__(256, (D == 64) ? 3 : 2) void attn_fwd_kernel(AttnFw
 #pragma unroll
       for (int d = 0; d < NDT; ++d) {
         const int roff = so + (32 * t + 16 * s2) * PITCH;
-        const bf16x8_t vf = tr_frag2(smem, v_lo[d] + roff, v_hi[d] + roff);
+        const bf16x8_t vf = tr_frag2a(v_lo[d] + (unsigned)roff, v_hi[d] + (unsigned)roff);
         ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, ot[d], 0, 0, 0);
       }
     }
   };
-  auto land = [&]() {   // this wave's outstanding DMAs have landed, and behind the barrier so have every wave's
+  auto land = [&]() __attribute__((always_inline)) {   // this wave's outstanding DMAs have landed, and behind the barrier so have every wave's
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   };
 
   f32x16_t sa, sb;   // raw scores of the half in progress / the half issued ahead
+  // Leading tiles that need no mask code: whole inside Sk, left of the causal edge, no key bias.  They run in a main loop
+  // unrolled over the ring (every stage offset is then a compile-time constant: the 12 swizzled fragment bases of a lane take
+  // immediate offsets instead of two VALU adds per LDS read — 52 of the 226 VALU instructions of a wave-tile, in a loop that
+  // is VALU-issue bound) and instantiated without the mask branch; the leftover and masked tiles take the rolled loop.
+  int n_plain = p.kbias ? 0 : p.Sk / 64;
+  if (p.causal && 2 * bx < n_plain) n_plain = 2 * bx;
+  if (nkt < n_plain) n_plain = nkt;
+  constexpr int STG = Cfg::STAGE;
+  int kt = 0;
   if constexpr (Cfg::NSTAGE >= 3) {
     // ring of three: tile kt+1 is awaited in the MIDDLE of tile kt (its first S^T chain is issued under the second half of tile
     // kt) and tile kt+2 is requested there, into the slot of tile kt-1 which every wave has left when it reaches that barrier
-    if (nkt > 0) {
-      land();
-      if (wave_active) issue_s(0, 0, sa);
-    }
-    for (int kt = 0; kt < nkt; ++kt) {
-      const int so = (kt % NSTAGE) * Cfg::STAGE, son = ((kt + 1) % NSTAGE) * Cfg::STAGE;
-      const bool more = kt + 1 < nkt;
+    auto step = [&](int kt, auto so_c, auto son_c, auto sreq_c, auto masked_c, auto more_c) __attribute__((always_inline)) {
+      const int so = so_c, son = son_c, sreq = sreq_c;
+      const bool more = decltype(more_c)::value || kt + 1 < nkt;
       if (wave_active) {
-        frame(sa, kt, 0);
+        frame(sa, kt, 0, masked_c);
         issue_s(so, 1, sb);                   // second half of this tile, under the exp2 / P.V of the first
         finish(sa, so, kt, 0);
       }
       if (more) {
         land();
-        if (kt + 2 < nkt) request(kt + 2);
+        if (kt + 2 < nkt) request(kt + 2, sreq);
       }
       if (wave_active) {
-        frame(sb, kt, 1);
+        frame(sb, kt, 1, masked_c);
         if (more) issue_s(son, 0, sa);        // first half of the next tile, under the exp2 / P.V of this one
         finish(sb, so, kt, 1);
       }
+    };
+    if (nkt > 0) {
+      land();
+      if (wave_active) issue_s(0, 0, sa);
     }
+    const std::true_type yes;
+    const std::false_type no;
+    for (; kt + 3 <= n_plain && kt + 3 < nkt; kt += 3) {   // (a tile follows the triple: `more` is known)
+      step(kt, CtOff<0>{}, CtOff<STG>{}, CtOff<2 * STG>{}, no, yes);
+      step(kt + 1, CtOff<STG>{}, CtOff<2 * STG>{}, CtOff<0>{}, no, yes);
+      step(kt + 2, CtOff<2 * STG>{}, CtOff<0>{}, CtOff<STG>{}, no, yes);
+    }
+    for (; kt < nkt; ++kt)
+      step(kt, RtOff{(kt % 3) * STG}, RtOff{((kt + 1) % 3) * STG}, RtOff{((kt + 2) % 3) * STG}, yes, no);
   } else {
     // ring of two (32-KiB stages at D >= 96): one barrier at the top of a tile, the next tile requested behind it
-    for (int kt = 0; kt < nkt; ++kt) {
-      const int so = (kt % NSTAGE) * Cfg::STAGE;
+    auto step = [&](int kt, auto so_c, auto son_c, auto masked_c) __attribute__((always_inline)) {
+      const int so = so_c, son = son_c;
       land();
-      if (kt + 1 < nkt) request(kt + 1);
+      if (kt + 1 < nkt) request(kt + 1, son);
       if (wave_active) {
         issue_s(so, 0, sa);
-        frame(sa, kt, 0);
+        frame(sa, kt, 0, masked_c);
         issue_s(so, 1, sb);
         finish(sa, so, kt, 0);
-        frame(sb, kt, 1);
+        frame(sb, kt, 1, masked_c);
         finish(sb, so, kt, 1);
       }
+    };
+    const std::true_type yes;
+    const std::false_type no;
+    for (; kt + 2 <= n_plain; kt += 2) {
+      step(kt, CtOff<0>{}, CtOff<STG>{}, no);
+      step(kt + 1, CtOff<STG>{}, CtOff<0>{}, no);
     }
+    for (; kt < nkt; ++kt) step(kt, RtOff{(kt % 2) * STG}, RtOff{((kt + 1) % 2) * STG}, yes);
   }
 
   // ---- normalise; O goes out through LDS as whole rows (the ring is free: every DMA has landed and been consumed) ----
   __builtin_amdgcn_s_barrier();   // all waves are past their last reads of the ring
   char* obuf = smem + wid * (32 * OP);
   {
+    const float lsum = lsum2[0] + lsum2[1];
     const float l_tot = lsum + __shfl_xor(lsum, 32, 64);
     const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
     if (p.lse2 && hh == 0 && qrow < p.Sq)
