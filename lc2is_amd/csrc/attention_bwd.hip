@@ -18,6 +18,8 @@
 #include "lc2is_hip.h"
 #include <type_traits>
 
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
 namespace {
 
 struct AttnBwdArgs {
@@ -234,12 +236,15 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dq_kernel(Att
           dpt[r] = drop_keep(p.drop, drop_rh, key) ? dpt[r] * p.drop.inv_keep : 0.f;
         }
       }
-      if constexpr (!MASKED) {  // interior tile: one fma + exp + sub + mul per score, no branches
-        const float neg_lse = -lse;
+      if constexpr (!MASKED) {  // interior tile: half a packed fma + exp + half a packed sub + half a packed mul per score, no branches
+        const f32x2_t sc2 = {p.scale_log2, p.scale_log2}, nl2 = {-lse, -lse}, dl2 = {delta, delta};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], p.scale_log2, neg_lse));
-          dpt[r] = pr * (dpt[r] - delta);
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2_t s2 = f32x2_t{st[r], st[r + 1]} * sc2 + nl2;                      // v_pk_fma_f32
+          const f32x2_t pr = {__builtin_amdgcn_exp2f(s2[0]), __builtin_amdgcn_exp2f(s2[1])};
+          const f32x2_t ds = pr * (f32x2_t{dpt[r], dpt[r + 1]} - dl2);                   // v_pk_add_f32, v_pk_mul_f32
+          dpt[r] = ds[0];
+          dpt[r + 1] = ds[1];
         }
       } else {
 #pragma unroll
@@ -401,8 +406,9 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(A
 
   // One tile of 64 queries.  DIAG (some key of the block may exceed some query of the tile: causal launches only) is a
   // compile-time property of the call site, so the non-causal body has no control flow (see the dQ kernel).
-  auto tile_body = [&](int qt, auto diag_c) {
+  auto tile_body = [&](int qt, auto diag_c, auto bias0_c) {
     constexpr bool DIAG = decltype(diag_c)::value;
+    constexpr bool BIAS0 = decltype(bias0_c)::value;   // every key of the block is a real key without a bias: s2 = s*scale - lse
     const int it = qt - qt0;
     const char* cur = smem + (it & 1) * STAGE;
     char* nxt = smem + ((it + 1) & 1) * STAGE;
@@ -438,9 +444,22 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(A
             dp[4 * c + j] *= keep4[j];
           }
         }
+        if constexpr (BIAS0 && !DIAG && !DROP) {   // the vision tower's body: packed fma / sub / mul, two scores per instruction
+          const f32x2_t sc2 = {p.scale_log2, p.scale_log2};
+#pragma unroll
+          for (int j = 0; j < 4; j += 2) {
+            const f32x2_t s2 = f32x2_t{sa[4 * c + j], sa[4 * c + j + 1]} * sc2 - f32x2_t{l4[j], l4[j + 1]};
+            const f32x2_t pr = {__builtin_amdgcn_exp2f(s2[0]), __builtin_amdgcn_exp2f(s2[1])};
+            const f32x2_t ds = pr * (f32x2_t{dp[4 * c + j], dp[4 * c + j + 1]} - f32x2_t{d4[j], d4[j + 1]});
+            sa[4 * c + j] = pr[0];
+            sa[4 * c + j + 1] = pr[1];
+            dp[4 * c + j] = ds[0];
+            dp[4 * c + j + 1] = ds[1];
+          }
+        } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          float s2 = __builtin_fmaf(sa[4 * c + j], p.scale_log2, bias) - l4[j];
+          float s2 = BIAS0 ? __builtin_fmaf(sa[4 * c + j], p.scale_log2, -l4[j]) : __builtin_fmaf(sa[4 * c + j], p.scale_log2, bias) - l4[j];
           if constexpr (DIAG) {
             const int q = qt * 64 + 32 * u + 8 * c + 4 * hh + j;
             if (kcol > q) s2 = -INF;
@@ -448,6 +467,7 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(A
           const float pr = __builtin_amdgcn_exp2f(s2);
           sa[4 * c + j] = DROP ? pr * keep4[j] : pr;     // dV takes the dropped probabilities
           dp[4 * c + j] = pr * (dp[4 * c + j] - d4[j]);
+        }
         }
       }
 #pragma unroll
@@ -472,8 +492,14 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(A
   // causal launches: the first tiles (queries up to the block's last key) straddle the diagonal, the rest lie below it
   int n_diag_end = qt0;
   if (p.causal) { n_diag_end = (bx * 128 + 127) / 64 + 1; if (n_diag_end > nqt) n_diag_end = nqt; }
-  for (int qt = qt0; qt < n_diag_end; ++qt) tile_body(qt, std::true_type{});
-  for (int qt = n_diag_end; qt < nqt; ++qt) tile_body(qt, std::false_type{});
+  const bool bias0 = p.kbias == nullptr && bx * 128 + 128 <= p.Sk;   // block-uniform
+  if (bias0) {
+    for (int qt = qt0; qt < n_diag_end; ++qt) tile_body(qt, std::true_type{}, std::true_type{});
+    for (int qt = n_diag_end; qt < nqt; ++qt) tile_body(qt, std::false_type{}, std::true_type{});
+  } else {
+    for (int qt = qt0; qt < n_diag_end; ++qt) tile_body(qt, std::true_type{}, std::false_type{});
+    for (int qt = n_diag_end; qt < nqt; ++qt) tile_body(qt, std::false_type{}, std::false_type{});
+  }
 
   if (kok) {
     bf16_t* krow = p.dK + (size_t)(b * p.Sk + kcol) * p.lddk + head * D;
