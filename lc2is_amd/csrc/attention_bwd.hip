@@ -90,8 +90,14 @@ __device__ __forceinline__ float dot8(const i32x4_t& a, const i32x4_t& b) {
 // DROP (both kernels): the forward dropped attention probabilities, O = (keep∘P / (1-p)) V.  Then dP = keep∘(dO V^T) / (1-p),
 // dV = (keep∘P / (1-p))^T dO, dS = P∘(dP − δ) with the UNDROPPED P and δ = rowsum(dO∘O) as before; keep is re-evaluated
 // from the same (row, key) coordinates as in attention_fwd.hip.
+#ifndef LC2IS_DQ_ATTR   // (experiment hooks: e.g. -DLC2IS_DQ_ATTR='__attribute__((amdgpu_waves_per_eu(2,2)))')
+#define LC2IS_DQ_ATTR
+#endif
+#ifndef LC2IS_DKDV_ATTR
+#define LC2IS_DKDV_ATTR
+#endif
 template <int D, bool DROP = false>
-__global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dq_kernel(AttnBwdArgs p) {
+__global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) LC2IS_DQ_ATTR void attn_bwd_dq_kernel(AttnBwdArgs p) {
   using I = Img<D>;
   constexpr int NKS = D / 16, NDT = D / 32, CH = I::CH, NCH = I::NCH;
   constexpr int STAGE = 2 * I::TILE + 256;  // K image, V image, 64 bias floats
@@ -305,7 +311,7 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dq_kernel(Att
 // (2) dK/dV kernel: grid (ceil(Sk/128), H, B), 4 waves x 32 keys; loops over 64-query tiles.
 // ------------------------------------------------------------------------------------------------------
 template <int D, bool DROP = false>
-__global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
+__global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) LC2IS_DKDV_ATTR void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
   using I = Img<D>;
   constexpr int NKS = D / 16, NDT = D / 32, CH = I::CH, NCH = I::NCH;
   constexpr int STAGE = 2 * I::TILE + 768;  // Q image, dO image, 64 lse2, 64 delta, 64 dropout row hashes
