@@ -14,11 +14,9 @@
 // The shared tiles are read BOTH by rows (ds_read_b128, MFMA A operand of S/dP) and by columns
 // (ds_read_b64_tr_b16, A operand of the transposed products) from ONE LDS image, made conflict-free for
 // both by an XOR swizzle of the 16-byte chunk index (128-byte rows for D=64, 256-byte rows otherwise).
-#include "common.h"
+#include "attn_common.h"
 #include "lc2is_hip.h"
-#include <type_traits>
-
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
+#include <cstdlib>
 
 namespace {
 
@@ -307,6 +305,295 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) LC2IS_DQ_ATTR void attn_bwd
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// (1b) dQ kernel, second form (the forward kernel's structure): K / V tiles arrive by LDS-DMA into a ring behind counted
+// s_waitcnt vmcnt + one raw s_barrier per tile (no staging registers, no ds_write pass), and the S^T / dP^T chains of the
+// next 32-key half tile are issued in the same basic block as the exp2 / dS arithmetic and the dQ products of the current one.
+// Interior tiles run unrolled over the ring (stage offsets are instruction immediates) without mask code; tail / causal-edge /
+// key-bias tiles take the rolled general body.  dQ rows leave through LDS as whole lines.
+// ------------------------------------------------------------------------------------------------------
+#ifndef LC2IS_DQ2_WAVES
+#define LC2IS_DQ2_WAVES 3
+#endif
+#ifndef LC2IS_DQ2_DP_AHEAD   // 1: the dP^T chain of the next half tile is issued ahead together with its S^T chain (16 more live registers)
+#define LC2IS_DQ2_DP_AHEAD 1
+#endif
+template <int D, bool DROP = false>
+__global__ __launch_bounds__(256, (D == 64) ? LC2IS_DQ2_WAVES : (D <= 96 ? 2 : 1)) void attn_bwd_dq2_kernel(AttnBwdArgs p) {
+  using Cfg = AttnCfg<D>;
+  constexpr int PITCH = Cfg::PITCH, NSTAGE = Cfg::NSTAGE, PD = NSTAGE - 1, STG = Cfg::STAGE;
+  constexpr int NKS = D / 16, NDT = D / 32;
+  constexpr int OP = 2 * D + 16;        // row pitch of the output staging image (bytes)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hh = lane >> 5, l31 = lane & 31;
+  const int nqb = (p.Sq + 127) / 128;   // 1-D XCD-aware grid (see attention_fwd.hip)
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int bx = tile % nqb, head = (tile / nqb) % p.H, b = tile / (nqb * p.H);
+  const int q0 = bx * 128 + wid * 32;
+  const int qrow = q0 + l31;
+  const bool qok = qrow < p.Sq;
+  const bool wave_active = q0 < p.Sq;   // wave-uniform
+  const float INF = __builtin_inff();
+  const unsigned drop_rh = DROP ? drop_row_hash(p.drop, (unsigned)((b * p.H + head) * p.Sq + qrow)) : 0u;
+
+  int nkt = (p.Sk + 63) / 64;
+  if (p.causal) {
+    const int lim = (bx * 128 + 128 + 63) / 64;
+    if (lim < nkt) nkt = lim;
+  }
+
+  const unsigned kbytes = (unsigned)p.B * p.Sk * p.ldk * 2u, vbytes = (unsigned)p.B * p.Sk * p.ldv * 2u;
+  int k_goff[Cfg::PPW], v_goff[Cfg::PPW];
+#pragma unroll
+  for (int j = 0; j < Cfg::PPW; ++j) {
+    const int row = Cfg::RPP * (wid * Cfg::PPW + j) + lane / Cfg::SLOTS;
+    const int ch = (lane % Cfg::SLOTS) ^ Cfg::swz(row);
+    k_goff[j] = ch < Cfg::CH ? ((b * p.Sk + row) * p.ldk + head * D + ch * 8) * 2 : -1;
+    v_goff[j] = ch < Cfg::CH ? ((b * p.Sk + row) * p.ldv + head * D + ch * 8) * 2 : -1;
+  }
+  auto request = [&](int kt, int so) __attribute__((always_inline)) {
+    attn_dma_tile<D>(p.K, kbytes, p.V, vbytes, smem + so, wid, k_goff, v_goff, kt * 64 * p.ldk * 2, kt * 64 * p.ldv * 2);
+  };
+#pragma unroll
+  for (int i = 0; i < PD; ++i)
+    if (i < nkt) request(i, i * STG);
+
+  // Q / dO fragments (B operands), delta = rowsum(dO . O) (written for the dK/dV kernel), the row's log-sum-exp
+  bf16x8_t qf[NKS], dof[NKS];
+  float dpart = 0.f;
+  {
+    const __amdgpu_buffer_rsrc_t rsQ = make_rsrc(p.Q, (unsigned)p.B * p.Sq * p.ldq * 2u);
+    const __amdgpu_buffer_rsrc_t rsO = make_rsrc(p.O, (unsigned)p.B * p.Sq * p.ldo * 2u);
+    const __amdgpu_buffer_rsrc_t rsdO = make_rsrc(p.dO, (unsigned)p.B * p.Sq * p.lddo * 2u);
+    const int tok = b * p.Sq + qrow;
+    const int qo = (tok * p.ldq + head * D + 8 * hh) * 2;
+    const int oo = (tok * p.ldo + head * D + 8 * hh) * 2;
+    const int go = (tok * p.lddo + head * D + 8 * hh) * 2;
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+      const i32x4_t qv = __builtin_amdgcn_raw_buffer_load_b128(rsQ, qok ? qo + s * 32 : -1, 0, 0);
+      const i32x4_t ov = __builtin_amdgcn_raw_buffer_load_b128(rsO, qok ? oo + s * 32 : -1, 0, 0);
+      const i32x4_t gv = __builtin_amdgcn_raw_buffer_load_b128(rsdO, qok ? go + s * 32 : -1, 0, 0);
+      qf[s] = __builtin_bit_cast(bf16x8_t, qv);
+      dof[s] = __builtin_bit_cast(bf16x8_t, gv);
+      dpart += dot8(ov, gv);
+    }
+  }
+  const float delta = dpart + __shfl_xor(dpart, 32, 64);
+  float lse = INF;  // padded query rows: exp2(x - inf) = 0
+  if (qok) {
+    const size_t si = ((size_t)b * p.H + head) * p.Sq + qrow;
+    const float l = p.lse2[si];
+    lse = (l == -INF) ? INF : l;
+    if (hh == 0) p.delta[si] = delta;
+  }
+
+  // opaque LDS fragment bases in stage 0 (attention_fwd.hip): K rows (V rows = + TILE), K transposed
+  const int q4 = (lane >> 2) & 3, p4 = lane & 3, cg = (lane >> 4) & 1;
+  const unsigned smem_a = (unsigned)(size_t)LDS_PTR(smem);
+  unsigned k_row[NKS], t_lo[NDT], t_hi[NDT];
+#pragma unroll
+  for (int s = 0; s < NKS; ++s) {
+    k_row[s] = smem_a + Cfg::off(l31, 2 * s + hh);
+    asm volatile("" : "+v"(k_row[s]));
+  }
+#pragma unroll
+  for (int d = 0; d < NDT; ++d) {
+    const int e = 32 * d + 16 * cg + 4 * p4;
+    t_lo[d] = smem_a + Cfg::off(4 * hh + q4, e >> 3) + (e & 7) * 2;
+    t_hi[d] = smem_a + Cfg::off(4 * hh + q4 + 8, e >> 3) + (e & 7) * 2;
+    asm volatile("" : "+v"(t_lo[d]), "+v"(t_hi[d]));
+  }
+
+  f32x16_t dq[NDT];
+#pragma unroll
+  for (int d = 0; d < NDT; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
+
+  // S^T = K.Q^T and dP^T = V.dO^T of one 32-key half tile
+  auto issue_s = [&](int so, int t, f32x16_t& st) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NKS; ++s)
+      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_read_b128(k_row[s] + (unsigned)(so + 32 * t * PITCH)), qf[s], st, 0, 0, 0);
+  };
+  auto issue_dp = [&](int so, int t, f32x16_t& dpt) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dpt[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NKS; ++s)
+      dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_read_b128(k_row[s] + (unsigned)(so + Cfg::TILE + 32 * t * PITCH)), dof[s], dpt,
+                                                    0, 0, 0);
+  };
+  auto issue = [&](int so, int t, f32x16_t& st, f32x16_t& dpt) __attribute__((always_inline)) {
+    issue_s(so, t, st);
+    if (LC2IS_DQ2_DP_AHEAD) issue_dp(so, t, dpt);
+  };
+  // P = exp2(s - lse), dS = P (dP - delta), dQ^T += K^T . dS^T
+  auto finish = [&](f32x16_t& st, f32x16_t& dpt, int so, int kt, int t, auto masked_c) __attribute__((always_inline)) {
+    constexpr bool MASKED = decltype(masked_c)::value;
+    if (!LC2IS_DQ2_DP_AHEAD) issue_dp(so, t, dpt);
+    if constexpr (DROP) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned key = (unsigned)(kt * 64 + 32 * t + 8 * (r >> 2) + 4 * hh + (r & 3));
+        dpt[r] = drop_keep(p.drop, drop_rh, key) ? dpt[r] * p.drop.inv_keep : 0.f;
+      }
+    }
+    const bool tail = (kt * 64 + 64 > p.Sk);
+    const bool diag = p.causal && (kt * 64 + 63 > bx * 128);
+    if (MASKED && (tail || diag || p.kbias != nullptr)) {   // masks go onto the RAW scores (scale_log2 > 0), then the common arithmetic
+      int key0 = kt * 64 + 32 * t + 4 * hh, qr = qrow;
+      asm volatile("" : "+v"(key0), "+v"(qr));
+      const float inv_sl2 = LOG2E / p.scale_log2;   // key bias in raw-score units
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int key = key0 + 8 * c + j;
+          float sc = st[4 * c + j];
+          if (key >= p.Sk) sc = -INF;
+          else if (p.kbias) sc += p.kbias[(size_t)b * p.Sk + key] * inv_sl2;
+          if (diag && key > qr) sc = -INF;
+          st[4 * c + j] = sc;
+        }
+    }
+    {
+      const f32x2_t sc2 = {p.scale_log2, p.scale_log2}, nl2 = {-lse, -lse}, dl2 = {delta, delta};
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2_t s2 = f32x2_t{st[r], st[r + 1]} * sc2 + nl2;
+        const f32x2_t pr = {__builtin_amdgcn_exp2f(s2[0]), __builtin_amdgcn_exp2f(s2[1])};
+        const f32x2_t ds = pr * (f32x2_t{dpt[r], dpt[r + 1]} - dl2);
+        dpt[r] = ds[0];
+        dpt[r + 1] = ds[1];
+      }
+    }
+#pragma unroll
+    for (int s2i = 0; s2i < 2; ++s2i) {
+      const bf16x8_t dsf = pack8(dpt, 8 * s2i);
+      const unsigned roff = (unsigned)(so + (32 * t + 16 * s2i) * PITCH);
+#pragma unroll
+      for (int d = 0; d < NDT; ++d) {
+        const bf16x8_t ktf = tr_frag2a(t_lo[d] + roff, t_hi[d] + roff);
+        dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf, dq[d], 0, 0, 0);
+      }
+    }
+  };
+  auto land = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+
+  int n_plain = p.kbias ? 0 : p.Sk / 64;
+  if (p.causal && 2 * bx < n_plain) n_plain = 2 * bx;
+  if (nkt < n_plain) n_plain = nkt;
+  const std::true_type yes;
+  const std::false_type no;
+  f32x16_t sa, da, sb, db;
+  int kt = 0;
+  if constexpr (NSTAGE >= 3) {
+    // interior tiles, pipelined: the chains of the next half tile are issued under the arithmetic / dQ products of the current one
+    auto step = [&](int kt, auto so_c, auto son_c, auto sreq_c) __attribute__((always_inline)) {
+      const int so = so_c, son = son_c, sreq = sreq_c;
+      if (wave_active) {
+        issue(so, 1, sb, db);
+        finish(sa, da, so, kt, 0, no);
+      }
+      __builtin_amdgcn_sched_barrier(0);   // a half step is the scheduling region: without the fences hipcc hoists the LDS reads of
+      land();                              // later half steps to the top of the unrolled triple and spills
+      if (kt + 2 < nkt) request(kt + 2, sreq);
+      __builtin_amdgcn_sched_barrier(0);
+      if (wave_active) {
+        issue(son, 0, sa, da);
+        finish(sb, db, so, kt, 1, no);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    if (nkt > 0) {
+      land();
+      if (wave_active) issue(0, 0, sa, da);
+    }
+    for (; kt + 3 <= n_plain && kt + 3 < nkt; kt += 3) {   // (a tile follows the triple)
+      step(kt, CtOff<0>{}, CtOff<STG>{}, CtOff<2 * STG>{});
+      step(kt + 1, CtOff<STG>{}, CtOff<2 * STG>{}, CtOff<0>{});
+      step(kt + 2, CtOff<2 * STG>{}, CtOff<0>{}, CtOff<STG>{});
+    }
+    // leftover and masked tiles: general body, one half tile live at a time (its per-score mask code needs the registers the
+    // look-ahead would hold; a rolled pipelined loop carries four 16-register accumulators around the back edge and spills,
+    // and scratch traffic counts in vmcnt, i.e. drains the DMA ring).  The first of them finds its first half already issued.
+    int nreq = kt + 2 < nkt ? kt + 2 : nkt;   // tiles requested so far
+    bool pre = nkt > 0;
+    for (; kt < nkt; ++kt) {
+      const int so = (kt % 3) * STG;
+      if (!pre) {
+        land();   // tile kt has landed; every wave has left tile kt-1, so the slots of tiles <= kt+2 are free
+        for (; nreq < nkt && nreq <= kt + 2; ++nreq) request(nreq, (nreq % 3) * STG);
+        if (wave_active) issue(so, 0, sa, da);
+      }
+      pre = false;
+      if (wave_active) {
+        finish(sa, da, so, kt, 0, yes);
+        issue(so, 1, sa, da);
+        finish(sa, da, so, kt, 1, yes);
+      }
+    }
+  } else {
+    auto step = [&](int kt, auto so_c, auto son_c, auto masked_c) __attribute__((always_inline)) {
+      const int so = so_c, son = son_c;
+      land();
+      if (kt + 1 < nkt) request(kt + 1, son);
+      if (wave_active) {
+        issue(so, 0, sa, da);
+        issue(so, 1, sb, db);
+        finish(sa, da, so, kt, 0, masked_c);
+        finish(sb, db, so, kt, 1, masked_c);
+      }
+    };
+    for (; kt + 2 <= n_plain; kt += 2) {
+      step(kt, CtOff<0>{}, CtOff<STG>{}, no);
+      step(kt + 1, CtOff<STG>{}, CtOff<0>{}, no);
+    }
+    for (; kt < nkt; ++kt) step(kt, RtOff{(kt % 2) * STG}, RtOff{((kt + 1) % 2) * STG}, yes);
+  }
+
+  // ---- dQ = scale * dq, out through LDS as whole rows (the ring is free: every DMA has landed and been consumed) ----
+  __builtin_amdgcn_s_barrier();
+  char* obuf = smem + wid * (32 * OP);
+#pragma unroll
+  for (int d = 0; d < NDT; ++d)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int col = 32 * d + 8 * c + 4 * hh;
+      *(uint2*)(obuf + l31 * OP + col * 2) = make_uint2(pack_bf16x2(dq[d][4 * c] * p.scale, dq[d][4 * c + 1] * p.scale),
+                                                        pack_bf16x2(dq[d][4 * c + 2] * p.scale, dq[d][4 * c + 3] * p.scale));
+    }
+  {
+    constexpr int CPR = D / 8;                   // 16-byte chunks per output row
+    constexpr int RPI = 64 / CPR;                // rows per store instruction
+    const __amdgpu_buffer_rsrc_t rsD = make_rsrc(p.dQ, (unsigned)p.B * p.Sq * p.lddq * 2u);
+    const int r_in = lane / CPR, ch = lane % CPR;
+    if (lane < RPI * CPR) {
+#pragma unroll
+      for (int it = 0; it < 32 / RPI + (32 % RPI ? 1 : 0); ++it) {
+        const int row = it * RPI + r_in;
+        if (row < 32) {
+          const i32x4_t v = *(const i32x4_t*)(obuf + row * OP + ch * 16);
+          const int qr = q0 + row;
+          const int off = (qr < p.Sq) ? ((b * p.Sq + qr) * p.lddq + head * D + ch * 8) * 2 : -1;
+          __builtin_amdgcn_raw_buffer_store_b128(v, rsD, off, 0, 0);
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // (2) dK/dV kernel: grid (ceil(Sk/128), H, B), 4 waves x 32 keys; loops over 64-query tiles.
 // ------------------------------------------------------------------------------------------------------
@@ -530,15 +817,24 @@ int launch_attn_bwd(const AttnBwdArgs& a, hipStream_t stream) {
   using I = Img<D>;
   constexpr int LDS_DQ = 2 * (2 * I::TILE + 256), LDS_KV = 2 * (2 * I::TILE + 768);
   auto k1 = attn_bwd_dq_kernel<D, DROP>;
+  auto k1b = attn_bwd_dq2_kernel<D, DROP>;
   auto k2 = attn_bwd_dkdv_kernel<D, DROP>;
+  using Cfg = AttnCfg<D>;
+  constexpr int OBUF = 4 * 32 * (2 * D + 16);
+  constexpr int LDS_DQ2 = Cfg::NSTAGE * Cfg::STAGE > OBUF ? Cfg::NSTAGE * Cfg::STAGE : OBUF;
+  static const bool dq_v2 = !(getenv("LC2IS_DQ_V2") && atoi(getenv("LC2IS_DQ_V2")) == 0);
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k1b, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ2) != hipSuccess ||
         hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_KV) != hipSuccess)
       return LC2IS_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL(k1, dim3(((a.Sq + 127) / 128) * a.H * a.B), dim3(256), LDS_DQ, stream, a);
+  if (dq_v2)
+    hipLaunchKernelGGL(k1b, dim3(((a.Sq + 127) / 128) * a.H * a.B), dim3(256), LDS_DQ2, stream, a);
+  else
+    hipLaunchKernelGGL(k1, dim3(((a.Sq + 127) / 128) * a.H * a.B), dim3(256), LDS_DQ, stream, a);
   int rc = lc2is_check_launch();
   if (rc) return rc;
   hipLaunchKernelGGL(k2, dim3(((a.Sk + 127) / 128) * a.H * a.B), dim3(256), LDS_KV, stream, a);
