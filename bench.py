@@ -53,7 +53,8 @@ SAMPLE_EVERY = 4   # HIP-event pairs around the dominant kernel on every 4th tim
 
 
 class GemmTimer:
-    """HIP-event timing of every call that runs the dominant kernel — gemm_nt_dma_kernel<256,256,2,4>, i.e. the NT GEMMs
+    """HIP-event timing of every call that runs the dominant kernel — the 256x256 LDS-DMA NT GEMM (gemm_nt_dma_kernel<256,256,2,4>
+    and its persistent form gemm_nt_persist2_kernel, same tile algebra), i.e. the NT GEMMs
     with >= 1024 128x128 tiles of output and N % 256 == 0 (the dispatch rule of lc2is_gemm_nt_bf16) — recorded on the
     stream the kernel is launched on.  (The small GEMMs of the text tower / decoder use other tile kernels and overlap
     the vision tower on a side stream; they are not part of this kernel's roofline.)"""
@@ -310,7 +311,7 @@ def main():
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "params_M": round(ts.arena.numel / 1e6, 2)},
             "final_loss": loss_val,
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_dma_kernel<256,256,2,4> (every launch of each 4th timed step)",
+            "roofline": {"bound": "mfma", "kernel": "256x256 LDS-DMA NT GEMM: gemm_nt_dma_kernel<256,256,2,4,0,*> + gemm_nt_persist2_kernel<*> (every launch of each 4th timed step)",
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(args)[0],
                          "traffic_source": pmc_traffic(args)[1],

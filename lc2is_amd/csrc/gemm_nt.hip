@@ -167,10 +167,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmNtArgs& p, f32x4_t (&acc
 // lane, 8 rows per wave instruction) through a private per-wave LDS patch, instead of 8-byte pieces whose
 // 32-byte row fragments cost partial-line writes.  fp32 residual / output keep the direct 16-B (64 B per row)
 // form.  Only in-order LDS traffic of one wave touches a patch, so no barrier is needed.
-template <int act, int TM, int TN, int WM, int WN>
+// RC (range-checked form, for the persistent kernel's counted s_waitcnt): every bf16 load / store of the epilogue is a buffer
+// access whose out-of-range lanes carry an offset beyond num_records (loads give 0, stores are dropped) — no branch around any
+// of them, so a wave issues EXACTLY 16 stores per bf16 output tensor and tile, whatever M and N are.
+struct NoHook { __device__ void operator()() const {} };
+// `loads_issued` (RC form) is called once, right after the LAST global load of the epilogue has returned (the bias rows when
+// the activation reads no saved tensor, else the second row group's saved pre-activations): the persistent kernel requests the
+// next tile's first K stage there, so that no wait of the epilogue is for something younger than those DMAs.
+template <int act, int TM, int TN, int WM, int WN, bool RC = false, typename Hook = NoHook>
 __device__ __forceinline__ void gemm_epilogue_lds_act(const GemmNtArgs& p, f32x4_t (&acc)[TN][TM], int m0, int n0,
-                                                      int wm, int wn, int lane, int wid, char* smem) {
+                                                      int wm, int wn, int lane, int wid, char* smem, Hook loads_issued = Hook()) {
   static_assert(WN == 64 && TM % 4 == 0, "staged epilogue expects 64-column wave tiles");
+  constexpr int OOB = 0x7fffffff;
+  const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.aux_in, (RC && p.aux_in) ? (unsigned)p.M * (unsigned)p.ldx * 2u : 0u);
+  const __amdgpu_buffer_rsrc_t rsY = make_rsrc(p.aux_out, (RC && p.aux_out) ? (unsigned)p.M * (unsigned)p.ldy * 2u : 0u);
+  const __amdgpu_buffer_rsrc_t rsO = make_rsrc(p.out_bf16, (RC && p.out_bf16) ? (unsigned)p.M * (unsigned)p.ldo * 2u : 0u);
   constexpr int PITCH = 144;                 // 128 B of data + 16: conflict-free ds_write_b64 / ds_read_b128
   char* patch = smem + wid * (64 * PITCH);
   const int frow = lane & 15, g = lane >> 4;
@@ -187,10 +198,11 @@ __device__ __forceinline__ void gemm_epilogue_lds_act(const GemmNtArgs& p, f32x4
     bvs[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     if (p.bias && n < p.N) bvs[i] = *(const f32x4_t*)(p.bias + n);
   }
+  if constexpr (RC && !has_aux) loads_issued();
 #pragma unroll
   for (int jg = 0; jg < TM / 4; ++jg) {
     const int mrow0 = m0 + wm * WM + jg * 64;
-    if (mrow0 >= p.M) break;  // wave-uniform
+    if (!RC && mrow0 >= p.M) break;  // wave-uniform
     // ---- (A) saved pre-activation / derivative for the backward epilogues: HBM -> patch (coalesced; the group's
     // eight loads are in flight together — requesting both groups up front costs 64 registers and spills) ----
     if (has_aux) {
@@ -199,10 +211,15 @@ __device__ __forceinline__ void gemm_epilogue_lds_act(const GemmNtArgs& p, f32x4
       for (int it = 0; it < 8; ++it) {
         const int m = mrow0 + it * 8 + srow;
         auxv[it] = i32x4_t{0, 0, 0, 0};
-        if (m < p.M && col_ok) auxv[it] = *(const i32x4_t*)(p.aux_in + (size_t)m * p.ldx + nw + sch * 8);
+        if constexpr (RC)
+          auxv[it] = __builtin_amdgcn_raw_buffer_load_b128(rsX, (m < p.M && col_ok) ? (m * p.ldx + nw + sch * 8) * 2 : OOB, 0, 0);
+        else if (m < p.M && col_ok) auxv[it] = *(const i32x4_t*)(p.aux_in + (size_t)m * p.ldx + nw + sch * 8);
       }
 #pragma unroll
       for (int it = 0; it < 8; ++it) *(i32x4_t*)(patch + (it * 8 + srow) * PITCH + sch * 16) = auxv[it];
+      // (behind the patch stores, i.e. once the loads have RETURNED: hipcc's vmcnt bookkeeping does not count LDS-DMA
+      //  instructions, so a wait for a load that has DMAs behind it turns into a wait for the DMAs as well)
+      if constexpr (RC) { if (jg == TM / 4 - 1) loads_issued(); }
     }
     // ---- (B) bias, derivative / pre-activation ----
 #pragma unroll
@@ -260,7 +277,9 @@ __device__ __forceinline__ void gemm_epilogue_lds_act(const GemmNtArgs& p, f32x4
       for (int it = 0; it < 8; ++it) {
         const int r = it * 8 + srow, m = mrow0 + r;
         const i32x4_t v = *(const i32x4_t*)(patch + r * PITCH + sch * 16);
-        if (m < p.M && col_ok) __builtin_nontemporal_store(v, (i32x4_t*)(p.aux_out + (size_t)m * p.ldy + nw + sch * 8));
+        if constexpr (RC)
+          __builtin_amdgcn_raw_buffer_store_b128(v, rsY, (m < p.M && col_ok) ? (m * p.ldy + nw + sch * 8) * 2 : OOB, 0, 2);   // nt
+        else if (m < p.M && col_ok) __builtin_nontemporal_store(v, (i32x4_t*)(p.aux_out + (size_t)m * p.ldy + nw + sch * 8));
       }
     }
     // ---- (D) activation, fp32 residual / output (direct), (E) bf16 output through the patch ----
@@ -277,7 +296,9 @@ __device__ __forceinline__ void gemm_epilogue_lds_act(const GemmNtArgs& p, f32x4
         for (int jl = 0; jl < 4; ++jl) {
           const int n = nw + (ip + ii) * 16 + g * 4, m = mrow0 + jl * 16 + frow;
           rv[ii][jl] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-          if (p.resid && m < p.M && n < p.N) rv[ii][jl] = *(const f32x4_t*)(p.resid + (size_t)m * p.ldr + n);
+          if constexpr (!RC) {   // (the RC form is for bf16 outputs without a residual)
+            if (p.resid && m < p.M && n < p.N) rv[ii][jl] = *(const f32x4_t*)(p.resid + (size_t)m * p.ldr + n);
+          }
         }
 #pragma unroll
       for (int ii = 0; ii < RPF; ++ii) {
@@ -299,7 +320,9 @@ __device__ __forceinline__ void gemm_epilogue_lds_act(const GemmNtArgs& p, f32x4
           }
           const bool ok = (m < p.M) && (n < p.N);
           v += rv[ii][jl];
-          if (p.out_f32 && ok) __builtin_nontemporal_store(v, (f32x4_t*)(p.out_f32 + (size_t)m * p.ldf + n));
+          if constexpr (!RC) {
+            if (p.out_f32 && ok) __builtin_nontemporal_store(v, (f32x4_t*)(p.out_f32 + (size_t)m * p.ldf + n));
+          }
           if (p.out_bf16) {
             i32x2_t pk = {(int)pack_bf16x2(v[0], v[1]), (int)pack_bf16x2(v[2], v[3])};
             *(i32x2_t*)(patch + (jl * 16 + frow) * PITCH + (i * 16 + g * 4) * 2) = pk;
@@ -312,7 +335,9 @@ __device__ __forceinline__ void gemm_epilogue_lds_act(const GemmNtArgs& p, f32x4
       for (int it = 0; it < 8; ++it) {
         const int r = it * 8 + srow, m = mrow0 + r;
         const i32x4_t v = *(const i32x4_t*)(patch + r * PITCH + sch * 16);
-        if (m < p.M && col_ok) __builtin_nontemporal_store(v, (i32x4_t*)(p.out_bf16 + (size_t)m * p.ldo + nw + sch * 8));
+        if constexpr (RC)
+          __builtin_amdgcn_raw_buffer_store_b128(v, rsO, (m < p.M && col_ok) ? (m * p.ldo + nw + sch * 8) * 2 : OOB, 0, 2);   // nt
+        else if (m < p.M && col_ok) __builtin_nontemporal_store(v, (i32x4_t*)(p.out_bf16 + (size_t)m * p.ldo + nw + sch * 8));
       }
     }
   }
@@ -566,6 +591,31 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_dma_kernel(Gemm
 #pragma unroll
     for (int i = 0; i < TN; ++i) wf0[i] = *(const bf16x8_t*)(smem + w_frag + i * 16 * 128 + kc_off0);
   }
+  if constexpr ((DBG & 8) != 0) {   // skeleton with 32x32x16 MFMAs: same FLOPs per K step (32 instead of 64 instructions), barrier per step
+    f32x16_t a32[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a32[i][r] = 0.f;
+    for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          bf16x8_t wv = wf0[(i + q) & 3], xv = xf0[(i * 3 + q) & 7];
+          asm volatile("" : "+v"(wv), "+v"(xv));
+          a32[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, xv, a32[i], 0, 0, 0);
+        }
+      __syncthreads();
+    }
+    float sacc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc += a32[i][r];
+    if (sacc == 1.2345e30f && p.out_f32) p.out_f32[0] = sacc;
+    return;
+  }
   for (int kt = 0; kt < nk; ++kt) {
     const char* cur = smem + (kt & 1) * STAGE;
     if constexpr ((DBG & 2) == 0) {
@@ -718,6 +768,112 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtArgs p, int 
       gemm_epilogue_lds_act<ACT, TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lane_e, wid, smem + STAGE);   // patches in stage 1 (+ 9 KiB)
     else
       gemm_epilogue_act<ACT, TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lane_e);
+    if (!more) break;
+  }
+}
+
+// ---- persistent form with counted waits across the tile seam (cfg 13) ------------------------------------------------------
+// As cfg 11, but the barrier that publishes the next tile's prefetched first stage no longer drains the epilogue's stores: gfx9
+// retires loads and stores of a wave in order through ONE counter, so with the first-stage DMAs issued BEFORE the epilogue and
+// exactly S stores after them (the RC epilogue: 16 per bf16 output tensor, no branch around any of them), `s_waitcnt vmcnt(S)`
+// means "the DMAs have landed" while the stores are still in flight.  They drain under the first K step of the next tile (the
+// second stage's DMA, issued behind them, is awaited with vmcnt(0) a full K step later).  bf16 outputs only (no fp32 residual).
+template <int ACT>
+__global__ __launch_bounds__(512) void gemm_nt_persist2_kernel(GemmNtArgs p, int ntiles) {
+  constexpr int BM = 256, BN = 256, WAVES_N = 4, BK = 64;
+  constexpr int WM = 128, WN = 64, TM = 8, TN = 4;
+  constexpr int A_PIECES = 4, W_PIECES = 4;
+  constexpr int STAGE = (BM + BN) * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int lane0 = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+  const int ntn = (p.N + BN - 1) / BN;
+  const unsigned a_bytes = (unsigned)p.M * (unsigned)p.lda * 2u, w_bytes = (unsigned)p.N * (unsigned)p.ldw * 2u;
+  const int nk = p.K / BK;
+  constexpr bool kAuxOut = ACT == LC2IS_ACT_QUICK_GELU || ACT == LC2IS_ACT_RELU || ACT == LC2IS_ACT_QUICK_GELU_GRAD ||
+                           ACT == LC2IS_ACT_GELU_ERF;
+  constexpr bool kAuxIn = ACT == LC2IS_ACT_DQUICK_GELU || ACT == LC2IS_ACT_DRELU || ACT == LC2IS_ACT_MUL_AUX || ACT == LC2IS_ACT_DGELU_ERF;
+  // stores a wave issues BEHIND the next tile's first-stage DMAs (RC epilogue; block-uniform): all 16 per output tensor when the
+  // DMAs go out after the bias loads, the second row group's 8 when they go out after that group's saved-tensor loads
+  const int nstores = ((p.out_bf16 ? 1 : 0) + ((kAuxOut && p.aux_out) ? 1 : 0)) * (kAuxIn ? 8 : 16);
+
+  auto first_stage = [&](int t, int lane) {
+    const int tile = xcd_remap(t, ntiles);
+    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+    const int lrow = lane >> 3, lch = (lane & 7) ^ (lane >> 3);
+    int a_goff[A_PIECES], w_goff[W_PIECES];
+#pragma unroll
+    for (int j = 0; j < A_PIECES; ++j) a_goff[j] = ((m0 + 8 * (wid * A_PIECES + j) + lrow) * p.lda + lch * 8) * 2;
+#pragma unroll
+    for (int j = 0; j < W_PIECES; ++j) w_goff[j] = ((n0 + 8 * (wid * W_PIECES + j) + lrow) * p.ldw + lch * 8) * 2;
+    dma_stage<BM, A_PIECES, W_PIECES>(p.A, a_bytes, p.W, w_bytes, smem, wid, a_goff, w_goff, 0);
+  };
+  auto publish = [&](int outstanding_stores) {   // the wave's DMAs have landed (stores issued behind them may still fly); then all waves'
+    if (outstanding_stores == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (outstanding_stores == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (outstanding_stores == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+
+  int t = blockIdx.x;
+  if (t >= ntiles) return;
+  first_stage(t, lane0);
+  int behind = 0;   // stores issued behind the pending first-stage DMAs
+  for (;;) {
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int tile = xcd_remap(t, ntiles);
+    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+    const int lrow = lane >> 3, lch = (lane & 7) ^ (lane >> 3);
+    int a_goff[A_PIECES], w_goff[W_PIECES];
+#pragma unroll
+    for (int j = 0; j < A_PIECES; ++j) a_goff[j] = ((m0 + 8 * (wid * A_PIECES + j) + lrow) * p.lda + lch * 8) * 2;
+#pragma unroll
+    for (int j = 0; j < W_PIECES; ++j) w_goff[j] = ((n0 + 8 * (wid * W_PIECES + j) + lrow) * p.ldw + lch * 8) * 2;
+    const int frow = lane & 15, g = lane >> 4, sw = lane & 7;
+    const int x_frag = (wm * WM + frow) * 128;
+    const int w_frag = BM * 128 + (wn * WN + frow) * 128;
+    const int kc_off0 = ((0 + g) ^ sw) << 4, kc_off1 = ((4 + g) ^ sw) << 4;
+
+    publish(behind);   // K tile 0 of this output tile has landed; the previous epilogue's patches (stage 1) are idle
+    f32x4_t acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nk; ++kt) {
+      const char* cur = smem + (kt & 1) * STAGE;
+      if (kt + 1 < nk)
+        dma_stage<BM, A_PIECES, W_PIECES>(p.A, a_bytes, p.W, w_bytes, smem + ((kt + 1) & 1) * STAGE, wid, a_goff, w_goff,
+                                          (kt + 1) * BK * 2);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int ko = ks ? kc_off1 : kc_off0;
+        bf16x8_t xf[TM], wf[TN];
+#pragma unroll
+        for (int j = 0; j < TM; ++j) xf[j] = *(const bf16x8_t*)(cur + x_frag + j * 16 * 128 + ko);
+#pragma unroll
+        for (int i = 0; i < TN; ++i) wf[i] = *(const bf16x8_t*)(cur + w_frag + i * 16 * 128 + ko);
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+      }
+      publish(0);   // everything older — the previous tile's stores included — has retired; the next K tile is published
+    }
+    t += gridDim.x;
+    const bool more = t < ntiles;
+    int lane_e = lane0;
+    asm volatile("" : "+v"(lane_e));
+    // stage 0 is free (every wave is past the last K step's barrier): the next tile's first stage is requested from inside the
+    // epilogue, behind its last global load; patches in stage 1 (+ 9 KiB)
+    gemm_epilogue_lds_act<ACT, TM, TN, WM, WN, true>(p, acc, m0, n0, wm, wn, lane_e, wid, smem + STAGE,
+                                                     [&]() { if (more) first_stage(t, lane_e); });
+    behind = nstores;
     if (!more) break;
   }
 }
@@ -1093,6 +1249,39 @@ int launch_persist_act(const GemmNtArgs& a, hipStream_t stream) {
   return lc2is_check_launch();
 }
 
+template <int ACT>
+int launch_persist2_act(const GemmNtArgs& a, hipStream_t stream) {
+  constexpr int LDS = (256 + 256) * 128 + 8 * 64 * 144;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm_nt_persist2_kernel<ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
+        hipSuccess)
+      return LC2IS_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int ntiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
+  const int grid = ntiles < 256 ? ntiles : 256;
+  hipLaunchKernelGGL(gemm_nt_persist2_kernel<ACT>, dim3(grid), dim3(512), LDS, stream, a, ntiles);
+  return lc2is_check_launch();
+}
+
+// the counted-wait persistent kernel takes bf16-output problems through the staged epilogue only (see the kernel's comment)
+bool persist2_ok(const GemmNtArgs& a) {
+  const double lim = 2147483648.0;
+  return a.staged_epi == 1 && a.out_bf16 && !a.out_f32 && !a.resid && a.K % 64 == 0 && (double)a.M * a.ldo * 2.0 < lim &&
+         (!a.aux_out || (double)a.M * a.ldy * 2.0 < lim) && (!a.aux_in || (double)a.M * a.ldx * 2.0 < lim);
+}
+
+int launch_persist2(const GemmNtArgs& a, hipStream_t stream) {
+  if (!persist2_ok(a)) return LC2IS_ERR_UNSUPPORTED;
+  switch (a.act) {
+    case LC2IS_ACT_QUICK_GELU: return launch_persist2_act<LC2IS_ACT_QUICK_GELU>(a, stream);
+    case LC2IS_ACT_DQUICK_GELU: return launch_persist2_act<LC2IS_ACT_DQUICK_GELU>(a, stream);
+    case LC2IS_ACT_NONE: return launch_persist2_act<LC2IS_ACT_NONE>(a, stream);
+    default: return LC2IS_ERR_UNSUPPORTED;
+  }
+}
+
 int launch_persist(const GemmNtArgs& a, hipStream_t stream) {
   switch (a.act) {
     case LC2IS_ACT_QUICK_GELU: return launch_persist_act<LC2IS_ACT_QUICK_GELU>(a, stream);
@@ -1189,6 +1378,7 @@ int launch_by_cfg(const GemmNtArgs& a_in, int cfg, hipStream_t stream) {
     case 10: return launch_dma<128, 384, 2, 4>(a, stream);
     case 11: return launch_persist(a, stream);
     case 12: return launch_dma<256, 256, 2, 2>(a, stream);      // 4 waves x (128x128): 2/3 of the LDS read traffic per FLOP
+    case 13: return launch_persist2(a, stream);
     case 48: return launch_dma<256, 256, 2, 2, 1>(a, stream);   // N = 768 / 2304: 3/4-size tiles, 64x96 per wave
     // diagnostic ablations of cfg 4 (wrong results by design; tools/gemm_ablate.py only)
     case 41: return launch_dma<256, 256, 2, 4, 1>(a, stream);
@@ -1196,6 +1386,7 @@ int launch_by_cfg(const GemmNtArgs& a_in, int cfg, hipStream_t stream) {
     case 43: return launch_dma<256, 256, 2, 4, 3>(a, stream);
     case 45: return launch_dma<256, 256, 2, 4, 5>(a, stream);
     case 47: return launch_dma<256, 256, 2, 4, 7>(a, stream);
+    case 49: return launch_dma<256, 256, 2, 4, 15>(a, stream);   // cfg 47's skeleton on 32x32x16 MFMAs
     default: return LC2IS_ERR_UNSUPPORTED;
   }
 }
@@ -1240,6 +1431,12 @@ extern "C" int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw
     else cfg = 3;                                        // small problem: 64x64 tiles to fill the chip
     return launch_by_cfg(a, cfg, stream);
   }
+  // bf16-output problems of >= 2 rounds of tiles: the persistent form with counted waits across the tile seam (cfg 13; ragged
+  // rows stay in the launch — its blocks walk the tiles, there is no round to save): -4..10 % on the K = 768 shapes
+  static const bool use_persist = !(getenv("LC2IS_GEMM_PERSIST") && atoi(getenv("LC2IS_GEMM_PERSIST")) == 0);
+  if (use_persist && persist2_ok(a) && (long)((M + 255) / 256) * (N / 256) >= 512 &&
+      (act == LC2IS_ACT_NONE || act == LC2IS_ACT_QUICK_GELU || act == LC2IS_ACT_DQUICK_GELU))
+    return launch_by_cfg(a, 13, stream);
   // Plenty of work: 256x256 LDS-DMA tiles, one block per CU, so time = rounds x tile cost; the ragged last <= 64 rows
   // (B x 1025 tokens: 32 rows) are peeled off into a small-tile launch when that saves a whole round of tiles.
   int best_cfg = 0, best_main = M;

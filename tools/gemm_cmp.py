@@ -35,7 +35,12 @@ for name, N, K, kind in cases:
     ref = mk(); run(cfgs[0], ref)
     line = []
     for cfg in cfgs:
-        o = mk(); run(cfg, o)
+        o = mk()
+        try:
+            run(cfg, o)
+        except RuntimeError:
+            line.append(f"cfg{cfg}=   n/a")
+            continue
         same = all(torch.equal(o[k], ref[k]) for k in ("o", "f") ) and (kind not in ("act", "act5") or torch.equal(o["z"], ref["z"]))
         t = min(timeit(lambda: run(cfg, o), iters=10, warm=2) for _ in range(3))
         line.append(f"cfg{cfg}={t*1e6:6.1f}us({2*M*N*K/t/1e12:5.0f}TF){'' if same else ' MISMATCH'}")

@@ -1,11 +1,11 @@
 """HBM bytes per launch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over bench.py.
 usage: pmc_sum.py <fetch counter_collection.csv> <write counter_collection.csv> <out prefix> [commit]
 Writes <prefix>_hbm_per_kernel.csv and <prefix>_hbm.json (the dominant kernel: every instantiation of
-gemm_nt_dma_kernel<256, 256, 2, 4, 0, *> aggregated).  Corrections per MI355X_MICROARCH.md (HBM section): FETCH_SIZE is KB
+gemm_nt_dma_kernel<256, 256, 2, 4, 0, *> and of its persistent form gemm_nt_persist2_kernel<*> aggregated).  Corrections per MI355X_MICROARCH.md (HBM section): FETCH_SIZE is KB
 and tallies 128-B requests at 64 B on gfx950 -> bytes = 2 x 1000 x FETCH_SIZE; WRITE_SIZE is KB, exact."""
 import collections, csv, json, re, sys
 
-DOM = "gemm_nt_dma_kernel<256, 256, 2, 4, 0"
+DOM = ("gemm_nt_dma_kernel<256, 256, 2, 4, 0", "gemm_nt_persist2_kernel<")   # the 256x256 LDS-DMA NT GEMM: plain and persistent forms
 
 
 def per_kernel(path, counter):
@@ -36,7 +36,7 @@ def main():
                     "hbm_bytes_per_launch"])
         for r in rows[:60]:
             w.writerow([r[0][:120] + (r[0][r[0].rfind(" grid="):] if " grid=" in r[0][120:] else ""), *r[1:]])
-    dom = [r for r in rows if DOM in r[0]]
+    dom = [r for r in rows if any(d in r[0] for d in DOM)]
     n = sum(r[1] for r in dom)
     rd = sum(r[1] * r[3] for r in dom) / n
     wr = sum(r[1] * r[4] for r in dom) / n
@@ -45,7 +45,7 @@ def main():
                       "--no-cpu-baseline (two separate passes, tools/prof_pmc.sh)",
            "corrections": "FETCH_SIZE is KB and tallies 128-B requests at 64 B on gfx950: bytes = 2 x 1000 x FETCH_SIZE; "
                           "WRITE_SIZE KB exact (MI355X_MICROARCH.md, HBM section)",
-           "kernel": DOM + ", *> (all epilogue instantiations, launch-weighted)", "launches": n,
+           "kernel": "gemm_nt_dma_kernel<256, 256, 2, 4, 0, *> + gemm_nt_persist2_kernel<*> (the 256x256 LDS-DMA NT GEMM, plain and persistent forms, all epilogue instantiations, launch-weighted)", "launches": n,
            "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr}
     json.dump(out, open(sys.argv[3] + "_hbm.json", "w"), indent=1)
     print(json.dumps(out))
