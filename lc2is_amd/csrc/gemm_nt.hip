@@ -1434,7 +1434,7 @@ extern "C" int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw
   // bf16-output problems of >= 2 rounds of tiles: the persistent form with counted waits across the tile seam (cfg 13; ragged
   // rows stay in the launch — its blocks walk the tiles, there is no round to save): -4..10 % on the K = 768 shapes
   static const bool use_persist = !(getenv("LC2IS_GEMM_PERSIST") && atoi(getenv("LC2IS_GEMM_PERSIST")) == 0);
-  static const long persist_min = getenv("LC2IS_GEMM_PERSIST_MIN") ? atol(getenv("LC2IS_GEMM_PERSIST_MIN")) : 512;
+  static const long persist_min = getenv("LC2IS_GEMM_PERSIST_MIN") ? atol(getenv("LC2IS_GEMM_PERSIST_MIN")) : 257;   // more than one round of tiles (A/B 512 -> 257: 907 -> 915 img/s)
   if (use_persist && persist2_ok(a) && (long)((M + 255) / 256) * (N / 256) >= persist_min &&
       (act == LC2IS_ACT_NONE || act == LC2IS_ACT_QUICK_GELU || act == LC2IS_ACT_DQUICK_GELU))
     return launch_by_cfg(a, 13, stream);
