@@ -109,6 +109,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + (bid >> 3);
 }
 
+// The same idea for grids that run as ROUNDS of 256 co-resident blocks (one block per CU) whose order matters (the grouped
+// weight-gradient grid: long blocks first, a finely split tail): inside every full round of 256, XCD x takes the round's 32
+// consecutive logical blocks 32x .. 32x+31, so the set of blocks of a round is unchanged; the ragged last round is chunked.
+__device__ __forceinline__ int xcd_round_remap(int bid, int nwg) {
+  const int full = nwg & ~255;
+  if (bid < full) return (bid & ~255) + ((bid & 7) << 5) + ((bid & 255) >> 3);
+  return full + xcd_remap(bid - full, nwg - full);
+}
+
 namespace {
 // out[c] (+)= sum_{k < nparts} ws[k*stride + c] for c < W (W, stride, ws_off_y multiples of 4; ws 16-byte aligned).
 // These launches sit between the big kernels of the backward and are latency-, not bandwidth-bound: block = 32 columns

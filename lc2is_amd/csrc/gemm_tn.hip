@@ -400,7 +400,7 @@ struct TnGroupProb {
   int red_blocks;   // slab blocks of the reduce grid (the rest of the problem's range sums the bias partials)
 };
 struct TnGroup {
-  int n;
+  int n, remap;
   TnGroupProb p[TG_MAX];
 };
 
@@ -416,15 +416,20 @@ struct TnGroupTbl {
 };
 constexpr size_t TG_TBL_BYTES = (sizeof(TnGroupTbl) + 255) / 256 * 256;
 
+// XCD-aware block order (t->pad_[0] / g.remap): blocks b, b+8, ... share an XCD and its L2, but neighbouring LOGICAL blocks are the
+// tiles of one problem, which share operand panels (a 256-column panel of dY serves K/256 tiles, one of X serves N/256): with the
+// plain order every tile streamed both of its panels from the Infinity Cache / HBM by itself — rocprofv3 FETCH_SIZE 38 GB per
+// whole-tower launch, 7.3 TB/s over its 5.2 ms.
 __global__ __launch_bounds__(512, 2) void gemm_tn_grouped_tbl_kernel(const TnGroupTbl* __restrict__ t) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int i = 0, begin = 0;
   const int n = t->n;
+  const int bid = t->pad_[0] ? xcd_round_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
 #pragma unroll 1
-  while (i < n - 1 && (int)blockIdx.x >= t->blk_end[i]) { begin = t->blk_end[i]; ++i; }
+  while (i < n - 1 && bid >= t->blk_end[i]) { begin = t->blk_end[i]; ++i; }
   const TnGroupProb* q = &t->p[i];
   tn_dma_body(q->dY, q->ldy, q->X, q->ldx, q->out, q->ldo, q->split_stride, q->bias_out, q->bias_split_stride, q->M, q->N,
-              q->K, q->ntn, q->ntk, q->chunk, q->splits == 1 ? q->accumulate : 0, (int)blockIdx.x - begin, smem);
+              q->K, q->ntn, q->ntk, q->chunk, q->splits == 1 ? q->accumulate : 0, bid - begin, smem);
 }
 
 // groups whose N / K are not all multiples of 256 (the Swin blocks: 96 .. 768 channels and their 4x MLPs) run the 128x128
@@ -453,11 +458,12 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_small_tbl_kernel(const Tn
 __global__ __launch_bounds__(512, 2) void gemm_tn_grouped_kernel(TnGroup g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int i = 0, begin = 0;
+  const int bid = g.remap ? xcd_round_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
 #pragma unroll 1
-  while (i < g.n - 1 && (int)blockIdx.x >= g.p[i].blk_end) { begin = g.p[i].blk_end; ++i; }
+  while (i < g.n - 1 && bid >= g.p[i].blk_end) { begin = g.p[i].blk_end; ++i; }
   const TnGroupProb& q = g.p[i];
   tn_dma_body(q.dY, q.ldy, q.X, q.ldx, q.out, q.ldo, q.split_stride, q.bias_out, q.bias_split_stride, q.M, q.N, q.K, q.ntn,
-              q.ntk, q.chunk, q.splits == 1 ? q.accumulate : 0, (int)blockIdx.x - begin, smem);
+              q.ntk, q.chunk, q.splits == 1 ? q.accumulate : 0, bid - begin, smem);
 }
 
 __device__ __forceinline__ void slab_reduce_grouped_body(const TnGroupProb& q, int b);
@@ -802,7 +808,9 @@ extern "C" int lc2is_gemm_tn_grouped(const lc2is_tn_problem* problems, int n, vo
     }
   }
   TnGroupTbl& t = captured_tbl ? *captured_tbl : (tbl ? *slot->host : small_tbl);
+  static const int xcd_order = !(getenv("LC2IS_TN_XCD") && atoi(getenv("LC2IS_TN_XCD")) == 0);
   t.n = n;
+  t.pad_[0] = xcd_order;
   float* ws = (float*)((char*)workspace + (tbl ? TG_TBL_BYTES : 0));
   int blk = 0, red = 0;
   for (int k = 0; k < n; ++k) {
@@ -870,6 +878,7 @@ extern "C" int lc2is_gemm_tn_grouped(const lc2is_tn_problem* problems, int n, vo
   }
   TnGroup g{};
   g.n = n;
+  g.remap = xcd_order;
   for (int k = 0; k < n; ++k) g.p[k] = t.p[k];
   if (pl.small)
     hipLaunchKernelGGL(gemm_tn_grouped_small_kernel, dim3(blk), dim3(256), 2 * TN_STAGE, stream, g);
