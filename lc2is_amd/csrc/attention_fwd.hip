@@ -10,13 +10,12 @@
 //
 // Work split: block = 4 waves = 128 queries of one (batch, head); each wave owns 32 queries.  Scores are
 // computed TRANSPOSED, S^T[key][query] = K·Q^T with 32x32x16 bf16 MFMAs, so a lane holds 16 keys of ONE
-// query per 32-key sub-tile: the online-softmax max/sum are per-lane loops plus one lane^32 exchange, and the
-// fp32 score registers, packed pairwise to bf16, are already the B operand of O^T[d][query] += V^T·P^T
-// (accumulator-as-operand, no LDS round trip).  V^T fragments come from the row-major V tile with
-// ds_read_b64_tr_b16.  K/V tiles of 64 keys are staged global->VGPR->LDS (range-checked loads), double
-// buffered, K rows padded by 16 B (conflict-free ds_read_b128), V rows at a 192/320-byte pitch
-// (conflict-free transposed reads).  Masks (key tail, key padding, causal) are an additive bias staged per
-// tile and only applied on tiles that need one.
+// query per 32-key half tile: the softmax max / sum are per-lane loops (the two lane halves of a row only talk when
+// the row's frame moves, see below), and the fp32 score registers, packed pairwise to bf16, are already the B operand
+// of O^T[d][query] += V^T·P^T (accumulator-as-operand, no LDS round trip).  V^T fragments come from the row-major V
+// tile with ds_read_b64_tr_b16.  K/V tiles of 64 keys arrive by LDS-DMA (buffer_load ... lds, range-checked, no staging
+// registers) into a ring of swizzled images (attn_common.h) that both kinds of read take without bank conflicts.
+// Masks (key tail, key padding, causal) are applied per score, only in tiles that need one.
 #include "attn_common.h"
 #include "lc2is_hip.h"
 #include <cstdlib>
