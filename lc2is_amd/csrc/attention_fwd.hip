@@ -35,7 +35,7 @@ struct AttnFwdArgs {
   DropCfg drop;         // attention-probability dropout (DROP instantiations only)
 };
 
-// Structure.  Measured on MI355X at S = 1025, D = 64 (rocprofv3 SQ counters, s_memtime phase stamps — tools/attn_stamp.sh —
+// Structure.  Measured on MI355X at S = 1025, D = 64 (rocprofv3 SQ counters — tools/pmc_attn.sh —, s_memtime phase stamps of a diagnostic build
 // and key-length sweeps — tools/attn_fixedcost.py): the launch costs 20 us + 8.25 us per 64-key tile, and a wave of the
 // un-pipelined form spends 3300 cycles per tile of which 2070 sit in ONE serial chain
 //     ds_read K -> 4 dependent MFMAs -> scale -> max -> branch -> exp2 -> pack -> ds_read V^T -> P.V
