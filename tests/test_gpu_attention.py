@@ -32,6 +32,12 @@ CASES = [
     (2, 8, 1024, 16, 96, False, True, False),     # decoder cross-attention with key padding
     (1, 2, 300, 200, 128, False, False, False),
     (1, 1, 129, 64, 64, False, False, False),
+    # round 2: the unrolled interior loops of the forward / dQ kernels and their hand-off to the general body
+    (1, 2, 400, 400, 64, True, False, True),      # causal over several query blocks: interior tiles left of the diagonal (2*bx of them)
+    (1, 1, 330, 330, 128, True, True, False),     # the same on the two-stage ring (D = 128), with key padding (no interior tiles)
+    (1, 2, 256, 512, 64, False, False, False),    # Sk a multiple of 64: every tile is interior, the last one leaves through the general body
+    (1, 1, 200, 448, 64, False, False, False),    # 7 tiles: two unrolled triples would overrun, one triple + 4 general tiles
+    (1, 1, 100, 832, 96, False, False, False),    # 13 tiles on the two-stage ring
 ]
 
 
