@@ -174,18 +174,18 @@ def cpu_baseline(arch_kwargs, in_size, out_size, L, sample_images, steps):
                 timed_step_s=[round(t, 3) for t in times[1:]])
 
 
-def pmc_traffic(args):
-    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary (profiles/r*_pmc_hbm.json, written
-    by tools/prof_pmc.sh + tools/pmc_sum.py: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command,
-    gfx950 corrections applied; the file names the commit it was taken at).  Counters cannot be read from inside the timed
-    process, so this is the recorded figure of that build, and only for the workload it was taken on.
-    Returns (bytes or None, source description or None)."""
-    prof = Path(__file__).resolve().parent / "profiles"
-    files = sorted(prof.glob("r*_pmc_hbm.json"))
-    if args.patch != 16 or args.batch != 32 or args.in_size != 512 or not files:
-        return None, None
-    rec = json.loads(files[-1].read_text())
-    return rec["hbm_bytes_per_launch"], f"profiles/{files[-1].name} @ {rec.get('commit', 'unrecorded commit')}"
+ROOFLINE_REF = ROOT / "profiles" / "roofline_ref.json"   # ONE explicit file, regenerated at HEAD by tools/prof_roofline.sh + tools/prof_pmc.sh
+STEP_GF_PER_IMG = 744.23    # algorithmic FLOPs of one train step per image, config 2 (SURVEY.md §8d / BASELINE.md §3)
+
+
+def profile_reference(args):
+    """Figures that cannot be measured from inside the timed process — PMC counters and per-kernel rocprofv3 durations — come
+    from ONE committed file, profiles/roofline_ref.json, which names the commit and the commands it was taken with
+    (tools/prof_roofline.sh: kernel traces of this same bench.py command and of the encoder alone; tools/prof_pmc.sh: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections applied).  They describe the headline workload only."""
+    if args.patch != 16 or args.batch != 32 or args.in_size != 512 or not ROOFLINE_REF.is_file():
+        return {}
+    return json.loads(ROOFLINE_REF.read_text())
 
 
 def main():
@@ -302,6 +302,7 @@ def main():
     if rank == 0:
         n_img = args.batch * world * args.steps
         achieved = gsum["flops"] / gsum["seconds"] / 1e12 if gsum["seconds"] > 0 else 0.0
+        ref = profile_reference(args)
         out = {
             "metric": f"training-step images/sec ({in_size}x{in_size}, ADE20K-150)", "value": n_img / dt, "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -313,8 +314,17 @@ def main():
             "final_loss": loss_val,
             "roofline": {"bound": "mfma", "kernel": "256x256 LDS-DMA NT GEMM: gemm_nt_dma_kernel<256,256,2,4,0,*> + gemm_nt_persist2_kernel<*> (every launch of each 4th timed step)",
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(args)[0],
-                         "traffic_source": pmc_traffic(args)[1],
+                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": ref.get("dominant_kernel_hbm_bytes_per_launch"),
+                         "traffic_source": (f"profiles/roofline_ref.json: {ref.get('dominant_kernel_hbm_source')}"
+                                            if ref.get("dominant_kernel_hbm_bytes_per_launch") else None),
+                         # the quantity the north_star target is stated in: whole step (live) and ViT encoder (rocprofv3)
+                         "step_frac": (STEP_GF_PER_IMG * 1e9 * (n_img / dt) / world / 1e12 / PEAK_BF16_TFLOPS
+                                       if args.patch == 16 and args.in_size == 512 else None),
+                         "encoder_frac": ref.get("encoder_frac"),
+                         "encoder_kernel_ms_per_step": ref.get("encoder_kernel_ms_per_step"),
+                         "bandwidth_kernels": [dict(kernel=b["kernel"], achieved_gbs=round(b["achieved_gbs"], 1), peak_gbs=8000.0,
+                                                    avg_us=round(b["avg_us"], 1)) for b in ref.get("bandwidth_kernels", [])],
+                         "profile_source": (f"profiles/roofline_ref.json @ {ref.get('commit')} ({ref.get('source')})" if ref else None),
                          "launches_per_step": gsum["launches"] / timed_steps, "hip_graph": use_graph,
                          "event_timed_steps": timed_steps,
                          "avg_launch_us": gsum["seconds"] / max(gsum["launches"], 1) * 1e6,

@@ -12,6 +12,7 @@ Every file is read with loaders that execute nothing from it (safetensors, ``tor
 """
 from __future__ import annotations
 
+import json
 from pathlib import Path
 
 import torch
@@ -35,12 +36,21 @@ def save_checkpoint(model: nn.Module, out_dir: str | Path, train_step: int) -> P
     d.mkdir(parents=True, exist_ok=True)
     f = d / f"step-{train_step}.pt"
     torch.save({k: v.detach().cpu() for k, v in model.state_dict().items()}, f)
+    # the dropout stream is not part of the reference's file (it would break the interchange): a JSON sidecar carries it, so a
+    # resumed run draws the masks the uninterrupted run would have drawn
+    from .nn.base import DropoutRng
+    if DropoutRng.get_state() is not None:
+        (d / f"step-{train_step}.rng.json").write_text(json.dumps({"dropout_rng_state": DropoutRng.get_state()}))
     return f
 
 
 def load_checkpoint(model: nn.Module, path: str | Path, strict: bool = True):
     """Load a reference ``step-N.pt`` (or one written by :func:`save_checkpoint`) into a drop-in model."""
     result = model.load_state_dict(_read_state(Path(path)), strict=strict)
+    side = Path(path).with_suffix(".rng.json")
+    if side.is_file():
+        from .nn.base import DropoutRng
+        DropoutRng.set_state(json.loads(side.read_text())["dropout_rng_state"])
     for m in model.modules():                      # bf16 weight shadows are rebuilt on the next forward
         if hasattr(m, "invalidate_shadows"):
             m.invalidate_shadows()

@@ -189,7 +189,9 @@ __global__ __launch_bounds__(256, (D == 64) ? 3 : 2) void attn_fwd_kernel(AttnFw
       const float mxx = fmaxf(mx, __shfl_xor(mx, 32, 64));            // the row's maximum over both lane halves
       const bool move = (mxx > FRAME_THR) || (!counted && mxx > NEG_INF);
       const float delta = move ? mxx : 0.f;
-      const float corr = __builtin_amdgcn_exp2f(-delta);             // 1 where nothing moves; O, l are 0 before the first key
+      // 1 where nothing moves.  A row's FIRST frame is not a rescale: O and l are exactly 0 and the dummy frame 0 means nothing,
+      // so exp2(-delta) must not be formed there (a first maximum below -128 gives +inf, and 0 * inf = NaN in O and l)
+      const float corr = counted ? __builtin_amdgcn_exp2f(-delta) : 1.f;
 #pragma unroll
       for (int d = 0; d < NDT; ++d)
 #pragma unroll

@@ -26,5 +26,7 @@ def compute_mIOU(outputs: torch.Tensor, labels: torch.Tensor, n_cls: int = 151, 
     present = lab > 0
     if ignore_index is not None:
         present[:, ignore_index] = False
-    per_img = (iou * present).sum(1) / present.sum(1).clamp_min(1)
+    # an image whose label holds nothing but ignore_index: the reference takes the mean of an EMPTY selection (metrics.py:94-97),
+    # which is NaN, and the mean over images (:101) inherits it — 0 / 0 here reproduces that instead of scoring the image 0
+    per_img = (iou * present).sum(1) / present.sum(1).to(torch.float64)
     return dict(mIOU_label=float(per_img.mean().item()))

@@ -67,20 +67,37 @@ def join_wgrad_stream(device) -> None:
 class DropoutRng:
     """Seeds for the counter-based dropout kernels (csrc/common.h).  Every dropout SITE of every forward draws one 64-bit
     seed; the site's backward re-uses it, so no mask is ever stored.  The stream is a splitmix64 sequence started from
-    ``torch.initial_seed()`` (so ``torch.manual_seed`` makes training runs repeatable) and the process' rank."""
+    ``torch.initial_seed()`` and the process' rank: ``torch.manual_seed`` makes training runs repeatable, and a LATER
+    ``torch.manual_seed`` restarts the stream (the torch seed is compared at every draw).  ``manual_seed`` sets the stream
+    directly; ``get_state`` / ``set_state`` travel with a checkpoint (checkpoint.save_checkpoint / load_checkpoint)."""
 
     _state = None
-    last = {}          # site name -> (seed, p) of the most recent forward, for tests that re-create the masks
+    _torch_seed = None  # the torch.initial_seed() the stream was derived from (or that was current at manual_seed / set_state)
+    last = {}           # site name -> (seed, p) of the most recent forward, for tests that re-create the masks.  Two blocks of
+                        # one model share site names ("layers.0.d1"): give each a distinct `rng_name` attribute (a string
+                        # prefix, default "") to keep their entries apart
 
     @classmethod
     def manual_seed(cls, seed: int) -> None:
         cls._state = seed & 0xFFFFFFFFFFFFFFFF
+        cls._torch_seed = torch.initial_seed()
+
+    @classmethod
+    def get_state(cls) -> int | None:
+        return cls._state
+
+    @classmethod
+    def set_state(cls, state: int | None) -> None:
+        cls._state = None if state is None else int(state) & 0xFFFFFFFFFFFFFFFF
+        cls._torch_seed = torch.initial_seed()
 
     @classmethod
     def next_seed(cls, site: str | None = None, p: float = 0.0) -> int:
-        if cls._state is None:
+        ts = torch.initial_seed()
+        if cls._state is None or ts != cls._torch_seed:
             rank = torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
-            cls._state = (torch.initial_seed() * 0x9E3779B97F4A7C15 + rank * 0xD1B54A32D192ED03 + 0x2545F4914F6CDD1D) & 0xFFFFFFFFFFFFFFFF
+            cls._state = (ts * 0x9E3779B97F4A7C15 + rank * 0xD1B54A32D192ED03 + 0x2545F4914F6CDD1D) & 0xFFFFFFFFFFFFFFFF
+            cls._torch_seed = ts
         cls._state = (cls._state + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
         z = cls._state
         z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF

@@ -295,7 +295,7 @@ class DecoderBlock(HipModule):
             kbias.masked_fill_(kpm, float("-inf"))
         saved = []
         for li, (layer, s) in enumerate(zip(self.layers, sh["layers"])):
-            ds = DropSites.make(self.training, layer.dropout_p, f"layers.{li}.")
+            ds = DropSites.make(self.training, layer.dropout_p, f"{getattr(self, 'rng_name', '')}layers.{li}.")
             x, sv = _layer_fwd(x, mem16, layer, s, B, Sq, Sk, kbias, save, ds)
             saved.append(sv)
         fin = None

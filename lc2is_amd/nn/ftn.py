@@ -244,7 +244,7 @@ class Transformer(HipModule):
             mem16, K = x16, P
         cur = P
         for r in range(self.repeat):
-            ds = DropSites.make(self.training, self.dropout_p, f"trans.{r}.")
+            ds = DropSites.make(self.training, self.dropout_p, f"{getattr(self, 'rng_name', '')}trans.{r}.")
             x32, x16, svl = _std_layer_fwd(x32, x16, mem16, self._layer(r), s, f"l{r}.", B, cur, K, save, ds)
             sv["layers"].append((svl, cur))
             if self.upsample:   # the grid height stays h (model/ftn.py:151-156)

@@ -308,7 +308,7 @@ class _SRBlock(HipModule):
         s = self._ensure_ready()
         saved = []
         for it in range(self.depth):     # the SAME layer `depth` times (shared weights), fresh dropout decisions each time
-            ds = DropSites.make(self.training, layer.dropout_p, f"sr{it}.")
+            ds = DropSites.make(self.training, layer.dropout_p, f"{getattr(self, 'rng_name', '')}sr{it}.")
             x32, x16, sv = _sr_layer_fwd(x32, x16, mem16, layer, s, B, P, K, save, ds)
             saved.append(sv)
         hw = _isqrt(P)

@@ -86,6 +86,8 @@ class TrainStep:
         Single-process only (the RCCL reduction is not captured)."""
         if self.reducer is not None:
             raise RuntimeError("TrainStep.capture: graph capture is only wired for single-GPU steps")
+        if self.kind == "adamw":   # (checked BEFORE anything runs or is captured)
+            raise RuntimeError("TrainStep.capture: AdamW bias correction is step-dependent; capture supports SGD")
         if hasattr(self.model, "overlap_text") and os.environ.get("LC2IS_GRAPH_OVERLAP", "1") == "0":
             self.model.overlap_text = False   # LC2IS_GRAPH_OVERLAP=0: one captured stream (default: the text-tower fork / join is captured too)
         from .nn.base import DropoutRng
@@ -106,8 +108,6 @@ class TrainStep:
         t_before = self.t
         with torch.cuda.graph(graph, stream=side):
             static_loss = self.step(static_in, static_lb)
-        if self.kind == "adamw":
-            raise RuntimeError("TrainStep.capture: AdamW bias correction is step-dependent; capture supports SGD")
         self.t = t_before   # capture records the step; nothing ran
 
         def replay(new_inputs: dict, new_labels: torch.Tensor) -> torch.Tensor:

@@ -230,7 +230,7 @@ def decoder_layer(sd: dict, pre: str, tgt: Tensor, memory: Tensor, nhead: int, n
     torch 2.10 the reference creates self_attn / linear1-2 / norm1-3 without them (SURVEY.md §2 drift #1).
     drop (training mode, :1158-1199): multipliers keep / (1 - p) for the six dropout sites — "sa_p", "ca_p"
     [B,H,Sq,Sk] on the attention probabilities, "d1", "d2", "d3" [B,Sq,C] on the branch outputs, "ff" [B,Sq,F] between
-    the activation and linear2; a missing key means no dropout at that site."""
+    the activation and linear2; a missing key means no dropout at that site.  "relu_mask": see ff() below."""
     g = lambda k: sd.get(pre + k)  # noqa: E731
     dm = (lambda name, t: t * drop[name] if (drop is not None and name in drop) else t)  # noqa: E731
     C = tgt.shape[-1]
@@ -257,8 +257,12 @@ def decoder_layer(sd: dict, pre: str, tgt: Tensor, memory: Tensor, nhead: int, n
         return dm("d2", linear(a, g("multihead_attn.out_proj.weight"), g("multihead_attn.out_proj.bias")))
 
     def ff(x):
-        return dm("d3", linear(dm("ff", torch.relu(linear(x, g("linear1.weight"), g("linear1.bias")))), g("linear2.weight"),
-                               g("linear2.bias")))
+        z = linear(x, g("linear1.weight"), g("linear1.bias"))
+        # "relu_mask" [B,Sq,F] (diagnostic input of the parity tests): the 0/1 activation pattern of ANOTHER run replaces this
+        # run's own sign test, act = z * mask — separates "which units fired" (a discontinuous choice that bf16 inputs flip
+        # for units next to zero) from the arithmetic downstream of it
+        act = z * drop["relu_mask"] if (drop is not None and "relu_mask" in drop) else torch.relu(z)
+        return dm("d3", linear(dm("ff", act), g("linear2.weight"), g("linear2.bias")))
 
     n = lambda i, x: layer_norm(x, g(f"norm{i}.weight"), g(f"norm{i}.bias"), eps)  # noqa: E731
     x = tgt
@@ -302,13 +306,14 @@ class BaseCfg:
     dec_layers: int = 1
 
 
-def base_model_with_text(sd: dict, inputs: dict, cfg: BaseCfg):
+def base_model_with_text(sd: dict, inputs: dict, cfg: BaseCfg, dec_drops: list | None = None):
     """BaseModelWithText.forward, literal operation order (model/model.py:27-56).
-    Returns (feature_t [K,512], feature_v [B,out²,512], logits [B,K,out,out])."""
+    Returns (feature_t [K,512], feature_v [B,out²,512], logits [B,K,out,out]).
+    dec_drops: per-decoder-layer multiplier dicts of decoder_layer (dropout masks / the diagnostic "relu_mask")."""
     enc_t = text_encoder_clip(sd, "text_encoder.", inputs["input_ids"], inputs["attention_mask"], cfg.text)
     enc_v = image_encoder_clip(sd, "vision_encoder.", inputs["pixel_values"], cfg.vision)
     kpm = inputs["attention_mask"] != 1
-    dec_v = decoder_block(sd, "vision_decoder.", enc_v, enc_t, cfg.dec_heads, cfg.dec_layers, True, kpm)
+    dec_v = decoder_block(sd, "vision_decoder.", enc_v, enc_t, cfg.dec_heads, cfg.dec_layers, True, kpm, drops=dec_drops)
     B, P, C = dec_v.shape
     H = cfg.in_size // cfg.patch
     x = dec_v.reshape(B, H, H, C).permute(0, 3, 1, 2)

@@ -57,3 +57,24 @@ def test_local_hub_snapshot_into_towers(tmp_path):
     torch.save(hub_s, d2 / "pytorch_model.bin")
     C.load_pretrained_dir(sw, d2)
     assert all(torch.equal(sw.state_dict()[k], ref_s[k] - 1) for k in ref_s)
+
+
+def test_dropout_rng_follows_torch_seed_and_travels_with_the_checkpoint(tmp_path):
+    """a later torch.manual_seed restarts the dropout stream; the stream state is saved beside step-N.pt
+    (JSON sidecar: the reference's file stays a plain state dict) and restored on load."""
+    from lc2is_amd.nn.base import DropoutRng
+    torch.manual_seed(5)
+    a = [DropoutRng.next_seed() for _ in range(3)]
+    torch.manual_seed(6)
+    b = [DropoutRng.next_seed() for _ in range(3)]
+    torch.manual_seed(5)
+    c = [DropoutRng.next_seed() for _ in range(3)]
+    assert a == c and a != b and len(set(a)) == 3
+    v, t = _tiny_arches()
+    m = N.BaseModelWithText(16, 64, 16, vision_arch=v, text_arch=t, nhead=1, dim_feedforward=128, out_dim=64, prototypes=torch.zeros(5, 64))
+    f = C.save_checkpoint(m, tmp_path, 3)
+    nxt = [DropoutRng.next_seed() for _ in range(2)]
+    DropoutRng.manual_seed(999)
+    C.load_checkpoint(m, f)
+    assert [DropoutRng.next_seed() for _ in range(2)] == nxt
+    assert isinstance(torch.load(f, weights_only=True), dict)                   # still the reference's format

@@ -38,6 +38,9 @@ CASES = [
     (1, 2, 256, 512, 64, False, False, False),    # Sk a multiple of 64: every tile is interior, the last one leaves through the general body
     (1, 1, 200, 448, 64, False, False, False),    # 7 tiles: two unrolled triples would overrun, one triple + 4 general tiles
     (1, 1, 100, 832, 96, False, False, False),    # 13 tiles on the two-stage ring
+    # round 3: config 5 at its real size — spatial-reduction attention of the 64x64 stage (queries 4096, keys 4096 / 4 after the
+    # 2x2 stride-2 conv, model/hierarchical.py:214-219), 8 heads x 64
+    (1, 8, 4096, 1024, 64, False, False, False),
 ]
 
 
@@ -82,6 +85,36 @@ def test_attention_fwd_spiked_scores(dev):
     o, _ = ops.attention_fwd(q, k, v, B, H, S, S, D, 0.125)
     ro, _, _ = _ref_attention(q, k, v, B, H, S, S, D, 0.125, False, None)
     assert (o.double() - ro).abs().max().item() < 3e-2
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_attention_very_negative_first_keys(dev, causal):
+    """A row whose FIRST half tile scores far below -128 in log2 units (q = +8, k[:64] = -8 at D = 64, scale 1: -4096):
+    the row's first frame must not be formed by rescaling the empty state (exp2(+4096) = inf, 0 * inf = NaN).  The causal
+    variant makes query 0 see only key 0 with a very negative q0.k0.  Forward and backward vs fp64."""
+    from lc2is_amd import ops
+    B, H, S, D = 1, 1, 192, 64
+    g = torch.Generator(device="cpu").manual_seed(5)
+    q = torch.randn(S, D, generator=g) * 0.125   # (ordinary rows: the usual 1/sqrt(D) score scale)
+    k = torch.randn(S, D, generator=g)
+    v = torch.randn(S, D, generator=g)
+    q[0] = 8.0
+    q[70] = 8.0
+    k[:64] = -8.0
+    q, k, v = (t.to(torch.bfloat16).to(dev) for t in (q, k, v))
+    do = torch.randn(S, D, generator=g).to(torch.bfloat16).to(dev)
+    o, lse2 = ops.attention_fwd(q, k, v, B, H, S, S, D, 1.0, causal=causal)
+    assert torch.isfinite(o.float()).all() and torch.isfinite(lse2).all()
+    qd, kd, vd = (t.double().clone().requires_grad_(True) for t in (q, k, v))
+    ro, rlse, _ = _ref_attention(qd, kd, vd, B, H, S, S, D, 1.0, causal, None)
+    assert (o.double() - ro.detach()).abs().max().item() < 3e-2
+    assert (lse2.double() * math.log(2.0) - rlse.detach()).abs().max().item() < 2e-2
+    dq, dk, dv = ops.attention_bwd(q, k, v, o, do, lse2, B, H, S, S, D, 1.0, causal=causal)
+    ro.backward(do.double())
+    for name, got, ref in (("dq", dq, qd.grad), ("dk", dk, kd.grad), ("dv", dv, vd.grad)):
+        assert torch.isfinite(got.float()).all(), name
+        rel = ((got.double() - ref).norm() / ref.norm().clamp_min(1e-30)).item()
+        assert rel < 3e-2, (name, rel)
 
 
 @pytest.mark.parametrize("B,H,Sq,Sk,D,causal,mask,packed", CASES)
