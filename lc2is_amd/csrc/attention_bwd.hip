@@ -83,242 +83,18 @@ __device__ __forceinline__ float dot8(const i32x4_t& a, const i32x4_t& b) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// (1) dQ kernel: grid (ceil(Sq/128), H, B), 4 waves x 32 queries; loops over 64-key tiles.
+// (1) dQ kernel: grid (ceil(Sq/128), H, B), 4 waves x 32 queries; loops over 64-key tiles (the forward kernel's structure):
+// K / V tiles arrive by LDS-DMA into a ring behind counted s_waitcnt vmcnt + one raw s_barrier per tile (no staging registers,
+// no ds_write pass), and the S^T / dP^T chains of the next 32-key half tile are issued in the same basic block as the exp2 / dS
+// arithmetic and the dQ products of the current one.  Interior tiles run unrolled over the ring (stage offsets are instruction
+// immediates) without mask code; tail / causal-edge / key-bias tiles take the rolled general body.  dQ rows leave through LDS
+// as whole lines.
 // ------------------------------------------------------------------------------------------------------
 // DROP (both kernels): the forward dropped attention probabilities, O = (keep∘P / (1-p)) V.  Then dP = keep∘(dO V^T) / (1-p),
 // dV = (keep∘P / (1-p))^T dO, dS = P∘(dP − δ) with the UNDROPPED P and δ = rowsum(dO∘O) as before; keep is re-evaluated
 // from the same (row, key) coordinates as in attention_fwd.hip.
-#ifndef LC2IS_DQ_ATTR   // (experiment hooks: e.g. -DLC2IS_DQ_ATTR='__attribute__((amdgpu_waves_per_eu(2,2)))')
-#define LC2IS_DQ_ATTR
-#endif
-#ifndef LC2IS_DKDV_ATTR
-#define LC2IS_DKDV_ATTR
-#endif
-template <int D, bool DROP = false>
-__global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) LC2IS_DQ_ATTR void attn_bwd_dq_kernel(AttnBwdArgs p) {
-  using I = Img<D>;
-  constexpr int NKS = D / 16, NDT = D / 32, CH = I::CH, NCH = I::NCH;
-  constexpr int STAGE = 2 * I::TILE + 256;  // K image, V image, 64 bias floats
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int hh = lane >> 5, l31 = lane & 31;
-  const int nqb = (p.Sq + 127) / 128;   // 1-D XCD-aware grid (see attention_fwd.hip)
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int bx = tile % nqb, head = (tile / nqb) % p.H, b = tile / (nqb * p.H);
-  const int qrow = bx * 128 + wid * 32 + l31;
-  const bool qok = qrow < p.Sq;
-  const bool wave_active = (int)(bx * 128 + wid * 32) < p.Sq;   // wave-uniform
-  const float INF = __builtin_inff();
-  const unsigned drop_rh = DROP ? drop_row_hash(p.drop, (unsigned)((b * p.H + head) * p.Sq + qrow)) : 0u;
-
-  int nkt = (p.Sk + 63) / 64;
-  if (p.causal) {
-    const int lim = (bx * 128 + 128 + 63) / 64;
-    if (lim < nkt) nkt = lim;
-  }
-
-  const __amdgpu_buffer_rsrc_t rsQ = make_rsrc(p.Q, (unsigned)p.B * p.Sq * p.ldq * 2u);
-  const __amdgpu_buffer_rsrc_t rsO = make_rsrc(p.O, (unsigned)p.B * p.Sq * p.ldo * 2u);
-  const __amdgpu_buffer_rsrc_t rsdO = make_rsrc(p.dO, (unsigned)p.B * p.Sq * p.lddo * 2u);
-  const __amdgpu_buffer_rsrc_t rsK = make_rsrc(p.K, (unsigned)p.B * p.Sk * p.ldk * 2u);
-  const __amdgpu_buffer_rsrc_t rsV = make_rsrc(p.V, (unsigned)p.B * p.Sk * p.ldv * 2u);
-
-  bf16x8_t qf[NKS], dof[NKS];
-  float dpart = 0.f;
-  {
-    const int tok = b * p.Sq + qrow;
-    const int qo = qok ? (tok * p.ldq + head * D + 8 * hh) * 2 : -1;
-    const int oo = qok ? (tok * p.ldo + head * D + 8 * hh) * 2 : -1;
-    const int go = qok ? (tok * p.lddo + head * D + 8 * hh) * 2 : -1;
-#pragma unroll
-    for (int s = 0; s < NKS; ++s) {
-      const i32x4_t qv = __builtin_amdgcn_raw_buffer_load_b128(rsQ, qok ? qo + s * 32 : -1, 0, 0);
-      const i32x4_t ov = __builtin_amdgcn_raw_buffer_load_b128(rsO, qok ? oo + s * 32 : -1, 0, 0);
-      const i32x4_t gv = __builtin_amdgcn_raw_buffer_load_b128(rsdO, qok ? go + s * 32 : -1, 0, 0);
-      qf[s] = __builtin_bit_cast(bf16x8_t, qv);
-      dof[s] = __builtin_bit_cast(bf16x8_t, gv);
-      dpart += dot8(ov, gv);
-    }
-  }
-  const float delta = dpart + __shfl_xor(dpart, 32, 64);
-  float lse = INF;  // padded query rows: exp2(x - inf) = 0
-  if (qok) {
-    const size_t si = ((size_t)b * p.H + head) * p.Sq + qrow;
-    const float l = p.lse2[si];
-    lse = (l == -INF) ? INF : l;
-    if (hh == 0) p.delta[si] = delta;
-  }
-
-  int k_goff[NCH], v_goff[NCH], t_lds[NCH];
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int c = tid + i * 256, row = c / CH, ch = c % CH;
-    k_goff[i] = ((b * p.Sk + row) * p.ldk + head * D + ch * 8) * 2;
-    v_goff[i] = ((b * p.Sk + row) * p.ldv + head * D + ch * 8) * 2;
-    t_lds[i] = I::off(row, ch);
-  }
-  i32x4_t rk[NCH], rv[NCH];
-  float rbias = 0.f;
-  auto gload = [&](int kt) {
-    const int kb = kt * 64 * p.ldk * 2, vb = kt * 64 * p.ldv * 2;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      rk[i] = __builtin_amdgcn_raw_buffer_load_b128(rsK, k_goff[i] + kb, 0, 0);
-      rv[i] = __builtin_amdgcn_raw_buffer_load_b128(rsV, v_goff[i] + vb, 0, 0);
-    }
-    if (tid < 64) {
-      const int key = kt * 64 + tid;
-      rbias = (key < p.Sk) ? (p.kbias ? p.kbias[(size_t)b * p.Sk + key] * LOG2E : 0.f) : -INF;
-    }
-  };
-  auto lstore = [&](char* stage) {
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      *(i32x4_t*)(stage + t_lds[i]) = rk[i];
-      *(i32x4_t*)(stage + I::TILE + t_lds[i]) = rv[i];
-    }
-    if (tid < 64) *(float*)(stage + 2 * I::TILE + tid * 4) = rbias;
-  };
-
-  const int q4 = (lane >> 2) & 3, p4 = lane & 3, cg = (lane >> 4) & 1;
-  // LDS addresses are hoisted out of the key loop: the swizzle only looks at row bits 0..3, so adding 16/32-row
-  // steps is a compile-time immediate on top of these per-lane bases (the XOR itself is not additive).
-  int row_addr[NKS], tr_lo[NDT], tr_hi[NDT];
-#pragma unroll
-  for (int s = 0; s < NKS; ++s) row_addr[s] = I::off(l31, 2 * s + hh);
-#pragma unroll
-  for (int d = 0; d < NDT; ++d) {
-    const int e = 32 * d + 16 * cg + 4 * p4;
-    tr_lo[d] = I::off(4 * hh + q4, e >> 3) + (e & 7) * 2;
-    tr_hi[d] = I::off(4 * hh + q4 + 8, e >> 3) + (e & 7) * 2;
-  }
-
-  f32x16_t dq[NDT];
-#pragma unroll
-  for (int d = 0; d < NDT; ++d)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
-
-  if (nkt > 0) {
-    gload(0);
-    lstore(smem);
-  }
-  __syncthreads();
-
-  // One tile of 64 keys.  MASKED is a compile-time property of the call site: the interior tiles of an unmasked launch (every
-  // tile of the vision tower but the last) run a body with NO control flow, which hipcc schedules as one block — the S^T / dP^T
-  // chains of the second 32-key half under the exp2 / dS arithmetic of the first; tail / key-padding / causal tiles take the
-  // general body (rocprofv3 SQ counters of the branchy form: VALU 45 % + MFMA 37 % busy, union 72 %: stalls between blocks).
-  auto tile_body = [&](int kt, auto masked_c) {
-    constexpr bool MASKED = decltype(masked_c)::value;
-    const char* cur = smem + (kt & 1) * STAGE;
-    char* nxt = smem + ((kt + 1) & 1) * STAGE;
-    const bool more = (kt + 1) < nkt;
-    if (more) gload(kt + 1);
-    const float* biasv = (const float*)(cur + 2 * I::TILE);
-    const bool diag = MASKED && p.causal && (kt * 64 + 63 > bx * 128);
-
-    if (wave_active) {   // waves past Sq (ragged last block) only help staging: one wave-uniform branch around the compute
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      f32x16_t st, dpt;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
-#pragma unroll
-      for (int s = 0; s < NKS; ++s) {
-        const int a = row_addr[s] + 32 * t * I::PITCH;
-        const bf16x8_t kf = *(const bf16x8_t*)(cur + a);
-        const bf16x8_t vf = *(const bf16x8_t*)(cur + I::TILE + a);
-        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st, 0, 0, 0);
-        dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[s], dpt, 0, 0, 0);
-      }
-      if constexpr (DROP) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const unsigned key = (unsigned)(kt * 64 + 32 * t + 8 * (r >> 2) + 4 * hh + (r & 3));
-          dpt[r] = drop_keep(p.drop, drop_rh, key) ? dpt[r] * p.drop.inv_keep : 0.f;
-        }
-      }
-      if constexpr (!MASKED) {  // interior tile: half a packed fma + exp + half a packed sub + half a packed mul per score, no branches
-        const f32x2_t sc2 = {p.scale_log2, p.scale_log2}, nl2 = {-lse, -lse}, dl2 = {delta, delta};
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const f32x2_t s2 = f32x2_t{st[r], st[r + 1]} * sc2 + nl2;                      // v_pk_fma_f32
-          const f32x2_t pr = {__builtin_amdgcn_exp2f(s2[0]), __builtin_amdgcn_exp2f(s2[1])};
-          const f32x2_t ds = pr * (f32x2_t{dpt[r], dpt[r + 1]} - dl2);                   // v_pk_add_f32, v_pk_mul_f32
-          dpt[r] = ds[0];
-          dpt[r + 1] = ds[1];
-        }
-      } else {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const f32x4_t bz = *(const f32x4_t*)(biasv + 32 * t + 8 * c + 4 * hh);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float s2 = st[4 * c + j] * p.scale_log2 + bz[j] - lse;
-            if (diag) {
-              const int key = kt * 64 + 32 * t + 8 * c + 4 * hh + j;
-              if (key > qrow) s2 = -INF;
-            }
-            const float pr = __builtin_amdgcn_exp2f(s2);
-            dpt[4 * c + j] = pr * (dpt[4 * c + j] - delta);
-          }
-        }
-      }
-#pragma unroll
-      for (int s2i = 0; s2i < 2; ++s2i) {
-        const bf16x8_t dsf = pack8(dpt, 8 * s2i);
-        const int roff = (32 * t + 16 * s2i) * I::PITCH;
-#pragma unroll
-        for (int d = 0; d < NDT; ++d) {
-          const bf16x8_t ktf = tr_frag3(cur, tr_lo[d] + roff, tr_hi[d] + roff);
-          dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf, dq[d], 0, 0, 0);
-        }
-      }
-    }
-    }  // wave_active
-    if (more) lstore(nxt);
-    __syncthreads();
-  };
-  // interior tiles first (full 64 keys, no bias, below the causal diagonal of every query of the block), then the rest
-  int n_plain = 0;
-  if (p.kbias == nullptr) {
-    n_plain = p.Sk / 64;                                   // tiles without a key tail
-    if (p.causal) { const int below = (bx * 128) / 64; if (below < n_plain) n_plain = below; }
-    if (n_plain > nkt) n_plain = nkt;
-  }
-  for (int kt = 0; kt < n_plain; ++kt) tile_body(kt, std::false_type{});
-  for (int kt = n_plain; kt < nkt; ++kt) tile_body(kt, std::true_type{});
-
-  if (qok) {
-    bf16_t* row = p.dQ + (size_t)(b * p.Sq + qrow) * p.lddq + head * D;
-#pragma unroll
-    for (int d = 0; d < NDT; ++d)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int col = 32 * d + 8 * c + 4 * hh;
-        uint2 pk = make_uint2(pack_bf16x2(dq[d][4 * c] * p.scale, dq[d][4 * c + 1] * p.scale),
-                              pack_bf16x2(dq[d][4 * c + 2] * p.scale, dq[d][4 * c + 3] * p.scale));
-        *reinterpret_cast<uint2*>(row + col) = pk;
-      }
-  }
-}
-
-
-// ------------------------------------------------------------------------------------------------------
-// (1b) dQ kernel, second form (the forward kernel's structure): K / V tiles arrive by LDS-DMA into a ring behind counted
-// s_waitcnt vmcnt + one raw s_barrier per tile (no staging registers, no ds_write pass), and the S^T / dP^T chains of the
-// next 32-key half tile are issued in the same basic block as the exp2 / dS arithmetic and the dQ products of the current one.
-// Interior tiles run unrolled over the ring (stage offsets are instruction immediates) without mask code; tail / causal-edge /
-// key-bias tiles take the rolled general body.  dQ rows leave through LDS as whole lines.
-// ------------------------------------------------------------------------------------------------------
-#ifndef LC2IS_DQ2_WAVES
-#define LC2IS_DQ2_WAVES 3
-#endif
-#ifndef LC2IS_DQ2_DP_AHEAD   // 1: the dP^T chain of the next half tile is issued ahead together with its S^T chain (16 more live registers)
-#define LC2IS_DQ2_DP_AHEAD 1
-#endif
+constexpr int LC2IS_DQ2_WAVES = 3;      // waves per SIMD the dQ kernel is compiled for at D = 64 (2 measured no slower)
+constexpr int LC2IS_DQ2_DP_AHEAD = 1;   // the dP^T chain of the next half tile is issued ahead together with its S^T chain (16 more live registers)
 template <int D, bool DROP = false>
 __global__ __launch_bounds__(256, (D == 64) ? LC2IS_DQ2_WAVES : (D <= 96 ? 2 : 1)) void attn_bwd_dq2_kernel(AttnBwdArgs p) {
   using Cfg = AttnCfg<D>;
@@ -598,7 +374,7 @@ __global__ __launch_bounds__(256, (D == 64) ? LC2IS_DQ2_WAVES : (D <= 96 ? 2 : 1
 // (2) dK/dV kernel: grid (ceil(Sk/128), H, B), 4 waves x 32 keys; loops over 64-query tiles.
 // ------------------------------------------------------------------------------------------------------
 template <int D, bool DROP = false>
-__global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) LC2IS_DKDV_ATTR void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
+__global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
   using I = Img<D>;
   constexpr int NKS = D / 16, NDT = D / 32, CH = I::CH, NCH = I::NCH;
   constexpr int STAGE = 2 * I::TILE + 768;  // Q image, dO image, 64 lse2, 64 delta, 64 dropout row hashes
@@ -815,26 +591,20 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) LC2IS_DKDV_ATTR void attn_b
 template <int D, bool DROP = false>
 int launch_attn_bwd(const AttnBwdArgs& a, hipStream_t stream) {
   using I = Img<D>;
-  constexpr int LDS_DQ = 2 * (2 * I::TILE + 256), LDS_KV = 2 * (2 * I::TILE + 768);
-  auto k1 = attn_bwd_dq_kernel<D, DROP>;
+  constexpr int LDS_KV = 2 * (2 * I::TILE + 768);
   auto k1b = attn_bwd_dq2_kernel<D, DROP>;
   auto k2 = attn_bwd_dkdv_kernel<D, DROP>;
   using Cfg = AttnCfg<D>;
   constexpr int OBUF = 4 * 32 * (2 * D + 16);
   constexpr int LDS_DQ2 = Cfg::NSTAGE * Cfg::STAGE > OBUF ? Cfg::NSTAGE * Cfg::STAGE : OBUF;
-  static const bool dq_v2 = !(getenv("LC2IS_DQ_V2") && atoi(getenv("LC2IS_DQ_V2")) == 0);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ) != hipSuccess ||
-        hipFuncSetAttribute((const void*)k1b, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ2) != hipSuccess ||
+    if (hipFuncSetAttribute((const void*)k1b, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ2) != hipSuccess ||
         hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_KV) != hipSuccess)
       return LC2IS_ERR_LAUNCH;
     attr_set = true;
   }
-  if (dq_v2)
-    hipLaunchKernelGGL(k1b, dim3(((a.Sq + 127) / 128) * a.H * a.B), dim3(256), LDS_DQ2, stream, a);
-  else
-    hipLaunchKernelGGL(k1, dim3(((a.Sq + 127) / 128) * a.H * a.B), dim3(256), LDS_DQ, stream, a);
+  hipLaunchKernelGGL(k1b, dim3(((a.Sq + 127) / 128) * a.H * a.B), dim3(256), LDS_DQ2, stream, a);
   int rc = lc2is_check_launch();
   if (rc) return rc;
   hipLaunchKernelGGL(k2, dim3(((a.Sk + 127) / 128) * a.H * a.B), dim3(256), LDS_KV, stream, a);

@@ -16,41 +16,10 @@
 // ds_read_b128 fragment reads bank-conflict free; the loads of tile t+1 are issued before the MFMAs of
 // tile t and written to the other LDS buffer after them (one barrier per K step).
 // Block ids are remapped so that each XCD (private L2) owns a contiguous run of tiles.
-#include "common.h"
-#include "lc2is_hip.h"
+#include "gemm_nt_common.h"
 #include <cstdlib>
 
 namespace {
-
-struct GemmNtArgs {
-  const bf16_t* A; int lda;
-  const bf16_t* W; int ldw;
-  const float* bias;
-  const float* resid; int ldr;
-  const bf16_t* aux_in; int ldx;
-  bf16_t* out_bf16; int ldo;
-  float* out_f32; int ldf;
-  bf16_t* aux_out; int ldy;
-  int M, N, K, act;
-  int staged_epi;  // 1: bf16 epilogue traffic through LDS (needs N % 8 == 0 and 8-element-aligned leading dims);
-                   // 2 (host side only, cleared before the launch): fp32-only output through LDS (F32EPI instantiations)
-  // strided-batched form (gemm_nt_kernel only; blockIdx.y = batch): element strides between consecutive problems
-  long bsA, bsW, bsOb, bsOf;
-};
-
-__device__ __forceinline__ float sigmoidf_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }  // v_exp + v_rcp
-// exact GELU of hf:activations.py "gelu" (Swin MLP, modeling_swin.py:474): 0.5 x (1 + erf(x / sqrt 2)) and its derivative
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
-// derivative = Phi(x) + x phi(x).  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 gradient it scales):
-// its exp(-(x/sqrt2)^2) IS the exp(-x^2/2) of phi, so the whole derivative is one v_exp, one v_rcp and seven FMAs — libm's
-// branchy erff() here made the DGELU_ERF epilogue spill 418 VGPRs (231 us per launch against 64 for the forward one).
-__device__ __forceinline__ float dgelu_erf(float x) {
-  const float e = __expf(-0.5f * x * x);
-  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * 0.70710678118654752f * __builtin_fabsf(x));
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float erf_abs = 1.0f - poly * e;
-  return 0.5f * (1.0f + __builtin_copysignf(erf_abs, x)) + x * 0.39894228040143268f * e;
-}
 
 // The activation code is a template parameter of both epilogues: with a run-time `act` inside the unrolled sub-tile
 // loops the kernels carried every variant inline (25k instructions for the 256x256 kernel, more than the instruction
@@ -533,10 +502,8 @@ __device__ __forceinline__ void dma_stage(const bf16_t* A, unsigned a_bytes, con
 // row l>>3) and the fragment reads use the same involution.  The DMA of tile t+1 is issued right after the
 // barrier that publishes tile t and flies during the MFMAs of tile t; the barrier's implicit vmcnt(0) retires
 // it.  256x256 tile, 8 waves (2x4), 128x64 per wave: 12 ds_read_b128 per 32 MFMAs.
-// DBG (diagnostic builds only, tools/gemm_ablate.py; results are WRONG by design): bit 0 = no epilogue,
-// bit 1 = no LDS-DMA inside the K loop (tile 0 is reused), bit 2 = fragments read once before the loop.
 // EPI: -1 = epilogue chosen at run time (p.act, p.staged_epi), 0..8 = that activation only, -2 = fp32-only output through LDS
-template <int BM, int BN, int WAVES_M, int WAVES_N, int DBG = 0, int EPI = -1>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI = -1>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_dma_kernel(GemmNtArgs p) {
   constexpr int NWAVE = WAVES_M * WAVES_N;
   constexpr int BK = 64;
@@ -584,60 +551,19 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_dma_kernel(Gemm
   dma_stage<BM, A_PIECES, W_PIECES>(p.A, a_bytes, p.W, w_bytes, smem, wid, a_goff, w_goff, 0);
   __syncthreads();  // emits s_waitcnt vmcnt(0): tile 0 has landed for every wave
 
-  bf16x8_t xf0[TM], wf0[TN];
-  if constexpr ((DBG & 4) != 0) {
-#pragma unroll
-    for (int j = 0; j < TM; ++j) xf0[j] = *(const bf16x8_t*)(smem + x_frag + j * 16 * 128 + kc_off0);
-#pragma unroll
-    for (int i = 0; i < TN; ++i) wf0[i] = *(const bf16x8_t*)(smem + w_frag + i * 16 * 128 + kc_off0);
-  }
-  if constexpr ((DBG & 8) != 0) {   // skeleton with 32x32x16 MFMAs: same FLOPs per K step (32 instead of 64 instructions), barrier per step
-    f32x16_t a32[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) a32[i][r] = 0.f;
-    for (int kt = 0; kt < nk; ++kt) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          bf16x8_t wv = wf0[(i + q) & 3], xv = xf0[(i * 3 + q) & 7];
-          asm volatile("" : "+v"(wv), "+v"(xv));
-          a32[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, xv, a32[i], 0, 0, 0);
-        }
-      __syncthreads();
-    }
-    float sacc = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sacc += a32[i][r];
-    if (sacc == 1.2345e30f && p.out_f32) p.out_f32[0] = sacc;
-    return;
-  }
   for (int kt = 0; kt < nk; ++kt) {
     const char* cur = smem + (kt & 1) * STAGE;
-    if constexpr ((DBG & 2) == 0) {
-      if (kt + 1 < nk)
-        dma_stage<BM, A_PIECES, W_PIECES>(p.A, a_bytes, p.W, w_bytes, smem + ((kt + 1) & 1) * STAGE, wid, a_goff, w_goff,
-                                          (kt + 1) * BK * 2);
-    }
+    if (kt + 1 < nk)
+      dma_stage<BM, A_PIECES, W_PIECES>(p.A, a_bytes, p.W, w_bytes, smem + ((kt + 1) & 1) * STAGE, wid, a_goff, w_goff,
+                                        (kt + 1) * BK * 2);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int ko = ks ? kc_off1 : kc_off0;
       bf16x8_t xf[TM], wf[TN];
-      if constexpr ((DBG & 4) != 0) {
 #pragma unroll
-        for (int j = 0; j < TM; ++j) { xf[j] = xf0[j]; asm volatile("" : "+v"(xf[j])); }
+      for (int j = 0; j < TM; ++j) xf[j] = *(const bf16x8_t*)(cur + x_frag + j * 16 * 128 + ko);
 #pragma unroll
-        for (int i = 0; i < TN; ++i) { wf[i] = wf0[i]; asm volatile("" : "+v"(wf[i])); }
-      } else {
-#pragma unroll
-        for (int j = 0; j < TM; ++j) xf[j] = *(const bf16x8_t*)(cur + x_frag + j * 16 * 128 + ko);
-#pragma unroll
-        for (int i = 0; i < TN; ++i) wf[i] = *(const bf16x8_t*)(cur + w_frag + i * 16 * 128 + ko);
-      }
+      for (int i = 0; i < TN; ++i) wf[i] = *(const bf16x8_t*)(cur + w_frag + i * 16 * 128 + ko);
 #pragma unroll
       for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -645,15 +571,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_dma_kernel(Gemm
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();  // all reads of `cur` done; DMA of the next tile retired (vmcnt(0)) and published
-  }
-  if constexpr ((DBG & 1) != 0) {
-    float sacc = 0.f;  // keep the accumulators alive without the store traffic
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-      for (int j = 0; j < TM; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-    if (sacc == 1.2345e30f && p.out_f32) p.out_f32[0] = sacc;
-    return;
   }
   if constexpr (EPI == -2) {   // its own instantiation: with all three epilogues in one kernel the allocator spills 400 VGPRs
     gemm_epilogue_f32_lds<TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lane, wid, smem);
@@ -671,105 +588,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_dma_kernel(Gemm
     }
   }
   gemm_epilogue<TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lane);
-}
-
-// ---- persistent form of the 256x256 LDS-DMA kernel (cfg 11) ---------------------------------------------------------
-// One block per CU walks tiles b, b+G, b+2G, ...  Per tile a K=768 GEMM spends ~13 us in the MFMA loop and nearly as long
-// around it (first-stage DMA latency, epilogue, block launch); here the first K tile of the NEXT output tile is requested
-// before the epilogue of the current one (its stage of LDS is free once the last K step's barrier has passed; the epilogue's
-// LDS patches live in the other stage), the epilogue's non-temporal stores drain under the next tile's MFMA loop, and there
-// is no per-tile block launch.
-template <int ACT>
-__global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtArgs p, int ntiles, int stagger) {
-  constexpr int BM = 256, BN = 256, WAVES_N = 4, BK = 64;
-  constexpr int WM = 128, WN = 64, TM = 8, TN = 4;
-  constexpr int A_PIECES = 4, W_PIECES = 4;
-  constexpr int STAGE = (BM + BN) * 128;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int lane0 = threadIdx.x & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wid / WAVES_N, wn = wid % WAVES_N;
-  const int ntn = (p.N + BN - 1) / BN;
-  const unsigned a_bytes = (unsigned)p.M * (unsigned)p.lda * 2u, w_bytes = (unsigned)p.N * (unsigned)p.ldw * 2u;
-  const int nk = p.K / BK;
-
-  // issue the first K tile of output tile `t` into stage 0 (per-lane offsets are temporaries of this call)
-  auto first_stage = [&](int t, int lane) {
-    const int tile = xcd_remap(t, ntiles);
-    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
-    const int lrow = lane >> 3, lch = (lane & 7) ^ (lane >> 3);
-    int a_goff[A_PIECES], w_goff[W_PIECES];
-#pragma unroll
-    for (int j = 0; j < A_PIECES; ++j) a_goff[j] = ((m0 + 8 * (wid * A_PIECES + j) + lrow) * p.lda + lch * 8) * 2;
-#pragma unroll
-    for (int j = 0; j < W_PIECES; ++j) w_goff[j] = ((n0 + 8 * (wid * W_PIECES + j) + lrow) * p.ldw + lch * 8) * 2;
-    dma_stage<BM, A_PIECES, W_PIECES>(p.A, a_bytes, p.W, w_bytes, smem, wid, a_goff, w_goff, 0);
-  };
-
-  int t = blockIdx.x;
-  if (t >= ntiles) return;
-  if (stagger > 0) {   // experiment: start the blocks of an XCD in 8 phases so that their epilogues do not coincide
-    const long long wait = (long long)((blockIdx.x >> 3) & 7) * stagger, t0 = wall_clock64();
-    while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(64);
-  }
-  first_stage(t, lane0);
-  for (;;) {
-    // every per-lane constant of the main loop is rebuilt per output tile from a laundered lane id, so nothing but the
-    // accumulators is live across the epilogue (which already sits at the 256-VGPR limit)
-    int lane = lane0;
-    asm volatile("" : "+v"(lane));
-    const int tile = xcd_remap(t, ntiles);
-    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
-    const int lrow = lane >> 3, lch = (lane & 7) ^ (lane >> 3);
-    int a_goff[A_PIECES], w_goff[W_PIECES];
-#pragma unroll
-    for (int j = 0; j < A_PIECES; ++j) a_goff[j] = ((m0 + 8 * (wid * A_PIECES + j) + lrow) * p.lda + lch * 8) * 2;
-#pragma unroll
-    for (int j = 0; j < W_PIECES; ++j) w_goff[j] = ((n0 + 8 * (wid * W_PIECES + j) + lrow) * p.ldw + lch * 8) * 2;
-    const int frow = lane & 15, g = lane >> 4, sw = lane & 7;
-    const int x_frag = (wm * WM + frow) * 128;
-    const int w_frag = BM * 128 + (wn * WN + frow) * 128;
-    const int kc_off0 = ((0 + g) ^ sw) << 4, kc_off1 = ((4 + g) ^ sw) << 4;
-
-    __syncthreads();  // vmcnt(0) + barrier: K tile 0 of this output tile has landed; the previous epilogue's patches are idle
-    f32x4_t acc[TN][TM];
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-      for (int j = 0; j < TM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    for (int kt = 0; kt < nk; ++kt) {
-      const char* cur = smem + (kt & 1) * STAGE;
-      if (kt + 1 < nk)
-        dma_stage<BM, A_PIECES, W_PIECES>(p.A, a_bytes, p.W, w_bytes, smem + ((kt + 1) & 1) * STAGE, wid, a_goff, w_goff,
-                                          (kt + 1) * BK * 2);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int ko = ks ? kc_off1 : kc_off0;
-        bf16x8_t xf[TM], wf[TN];
-#pragma unroll
-        for (int j = 0; j < TM; ++j) xf[j] = *(const bf16x8_t*)(cur + x_frag + j * 16 * 128 + ko);
-#pragma unroll
-        for (int i = 0; i < TN; ++i) wf[i] = *(const bf16x8_t*)(cur + w_frag + i * 16 * 128 + ko);
-#pragma unroll
-        for (int i = 0; i < TN; ++i)
-#pragma unroll
-          for (int j = 0; j < TM; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-      }
-      __syncthreads();
-    }
-    t += gridDim.x;
-    const bool more = t < ntiles;
-    int lane_e = lane0;
-    asm volatile("" : "+v"(lane_e));
-    if (more) first_stage(t, lane_e);   // stage 0 is free (every wave is past the last K step's barrier)
-    if (p.staged_epi)   // one activation variant per kernel instantiation: with all nine inside this loop the allocator spills 600 VGPRs
-      gemm_epilogue_lds_act<ACT, TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lane_e, wid, smem + STAGE);   // patches in stage 1 (+ 9 KiB)
-    else
-      gemm_epilogue_act<ACT, TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lane_e);
-    if (!more) break;
-  }
 }
 
 // ---- persistent form with counted waits across the tile seam (cfg 13) ------------------------------------------------------
@@ -878,327 +696,6 @@ __global__ __launch_bounds__(512) void gemm_nt_persist2_kernel(GemmNtArgs p, int
   }
 }
 
-// ---- ping-pong variant: the two waves of every SIMD alternate LDS-read and MFMA segments ------------------
-// 256x256x64 tile, 8 waves (2x4, 128x64 each).  Waves 0-3 and 4-7 pair up on the four SIMDs; the second group runs
-// one barrier behind the first, so between any two barriers one wave of each SIMD issues its 12 ds_read_b128 (and,
-// once per K tile, its 8 LDS-DMA pieces) while its partner issues 32 MFMAs from registers: the matrix pipe never
-// waits for LDS.  The DMA is issued from inline asm (global_load_lds_dwordx4) so that hipcc, which would
-// otherwise drain vmcnt(0) before the next ds_read, leaves it in flight across three barriers; its completion
-// is waited by hand (vmcnt(0)) before the barrier that precedes the first read of the tile.
-//   interval 4t+1 : both groups issue the DMA of K tile t+1 into the other buffer (all reads of that buffer
-//                   retired two barriers earlier)
-//   interval 4t+3 : both groups wait vmcnt(0) before the closing barrier; tile t+1 is first read in interval 4t+4
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(gsrc), "s"(lds_dst)
-               : "memory");
-}
-
-__global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmNtArgs p) {
-  constexpr int BM = 256, BN = 256, WAVES_N = 4, BK = 64;
-  constexpr int WM = 128, WN = 64, TM = 8, TN = 4;
-  constexpr int PIECES = 4;  // 1-KiB pieces (8 rows x 128 B) per wave per operand tile
-  constexpr int STAGE = (BM + BN) * 128;
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)LDS_PTR(smem);
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid / WAVES_N, wn = wid % WAVES_N;
-  const int grp = wm;  // waves 0-3: group 0, waves 4-7: group 1 (SIMD partners)
-  const int ntn = (p.N + BN - 1) / BN;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
-
-  // per-lane DMA sources (rows clamped into the matrix: rows past M / N only feed outputs that are never stored)
-  const int lrow = lane >> 3, lch = (lane & 7) ^ (lane >> 3);
-  const char* a_src[PIECES];
-  const char* w_src[PIECES];
-#pragma unroll
-  for (int j = 0; j < PIECES; ++j) {
-    int ar = m0 + 8 * (wid * PIECES + j) + lrow;
-    int wr = n0 + 8 * (wid * PIECES + j) + lrow;
-    ar = ar < p.M ? ar : p.M - 1;
-    wr = wr < p.N ? wr : p.N - 1;
-    a_src[j] = (const char*)p.A + ((size_t)ar * p.lda + lch * 8) * 2;
-    w_src[j] = (const char*)p.W + ((size_t)wr * p.ldw + lch * 8) * 2;
-  }
-  const unsigned a_dst = lds_base + wid * PIECES * 1024;
-  const unsigned w_dst = lds_base + BM * 128 + wid * PIECES * 1024;
-
-#define PP_ISSUE(BUF, KB)                                                        \
-  do {                                                                           \
-    _Pragma("unroll") for (int j = 0; j < PIECES; ++j)                           \
-        glds16(a_src[j] + (KB), a_dst + (BUF)*STAGE + j * 1024);                 \
-    _Pragma("unroll") for (int j = 0; j < PIECES; ++j)                           \
-        glds16(w_src[j] + (KB), w_dst + (BUF)*STAGE + j * 1024);                 \
-  } while (0)
-#define PP_BARRIER()                          \
-  do {                                        \
-    __builtin_amdgcn_sched_barrier(0);        \
-    __builtin_amdgcn_s_barrier();             \
-    __builtin_amdgcn_sched_barrier(0);        \
-  } while (0)
-#define PP_WAIT_DMA() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-
-  f32x4_t acc[TN][TM];
-#pragma unroll
-  for (int i = 0; i < TN; ++i)
-#pragma unroll
-    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  const int frow = lane & 15, g = lane >> 4, sw = lane & 7;
-  const int x_frag = (wm * WM + frow) * 128;
-  const int w_frag = BM * 128 + (wn * WN + frow) * 128;
-  const int kc_off0 = ((0 + g) ^ sw) << 4, kc_off1 = ((4 + g) ^ sw) << 4;
-  const int nk = p.K / BK;
-
-  PP_ISSUE(0, 0);
-  PP_WAIT_DMA();
-  PP_BARRIER();
-  if (grp == 1) PP_BARRIER();  // stagger: group 1 runs one segment behind group 0
-
-  bf16x8_t xf[TM], wf[TN];
-  for (int kt = 0; kt < nk; ++kt) {
-    const char* cur = smem + (kt & 1) * STAGE;
-    const int nbuf = (kt + 1) & 1;
-    const bool more = (kt + 1) < nk;
-    const int kb = (kt + 1) * BK * 2;
-    // ---- phase k-substep 0: LOAD segment ----
-    if (grp == 1 && more) PP_ISSUE(nbuf, kb);
-#pragma unroll
-    for (int j = 0; j < TM; ++j) xf[j] = *(const bf16x8_t*)(cur + x_frag + j * 16 * 128 + kc_off0);
-#pragma unroll
-    for (int i = 0; i < TN; ++i) wf[i] = *(const bf16x8_t*)(cur + w_frag + i * 16 * 128 + kc_off0);
-    PP_BARRIER();
-    // ---- COMPUTE segment ----
-    if (grp == 0 && more) PP_ISSUE(nbuf, kb);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-      for (int j = 0; j < TM; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    PP_BARRIER();
-    // ---- phase k-substep 1: LOAD segment ----
-#pragma unroll
-    for (int j = 0; j < TM; ++j) xf[j] = *(const bf16x8_t*)(cur + x_frag + j * 16 * 128 + kc_off1);
-#pragma unroll
-    for (int i = 0; i < TN; ++i) wf[i] = *(const bf16x8_t*)(cur + w_frag + i * 16 * 128 + kc_off1);
-    if (grp == 1) PP_WAIT_DMA();
-    PP_BARRIER();
-    // ---- COMPUTE segment ----
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-      for (int j = 0; j < TM; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    if (grp == 0) PP_WAIT_DMA();
-    PP_BARRIER();
-  }
-  if (grp == 0) PP_BARRIER();  // even out the barrier count
-  __syncthreads();
-#undef PP_ISSUE
-#undef PP_BARRIER
-#undef PP_WAIT_DMA
-  if (p.staged_epi)
-    gemm_epilogue_lds<TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lane, wid, smem);
-  else
-    gemm_epilogue<TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lane);
-}
-
-// ---- ring variant: 4-deep LDS ring of 32-wide K slices, LDS-DMA kept 2-3 slices ahead ------------------------
-// PMC on the two-buffer kernel shows the matrix pipe busy only ~45 % with the waves parked at the per-tile barrier:
-// one K tile (~1 us) of lookahead does not cover the L2/MALL latency of the LDS-DMA under load.  Here the 256x256
-// tile is fed through FOUR 32 KiB stages (K slice = 32); the DMA for slice t+3 is issued right after the barrier
-// of slice t and waited with a COUNTED s_waitcnt vmcnt(8) (two younger slices stay in flight) — never vmcnt(0) in
-// the main loop.  64-byte LDS rows use the chunk swizzle  c ^= (-(row>>2)) & 3  (conflict-free for the
-// ds_read_b128 lane groups); accumulation order equals the other kernels' (bitwise-equal results).
-__global__ __launch_bounds__(512) void gemm_nt_ring_kernel(GemmNtArgs p) {
-  constexpr int BM = 256, BN = 256, WAVES_N = 4, BK = 32, NST = 4;
-  constexpr int WM = 128, WN = 64, TM = 8, TN = 4;
-  constexpr int PIECES = 2;               // 1-KiB pieces (16 rows x 64 B) per wave per operand per stage
-  constexpr int STAGE = (BM + BN) * 64;   // 32 KiB
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)LDS_PTR(smem);
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid / WAVES_N, wn = wid % WAVES_N;
-  const int ntn = (p.N + BN - 1) / BN;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
-
-  const int lrow = lane >> 2, lch = (lane & 3) ^ ((-(lane >> 4)) & 3);  // (row>>2)&3 == lane>>4 inside a 16-row piece
-  const char* a_src[PIECES];
-  const char* w_src[PIECES];
-#pragma unroll
-  for (int j = 0; j < PIECES; ++j) {
-    int ar = m0 + 16 * (wid * PIECES + j) + lrow;
-    int wr = n0 + 16 * (wid * PIECES + j) + lrow;
-    ar = ar < p.M ? ar : p.M - 1;
-    wr = wr < p.N ? wr : p.N - 1;
-    a_src[j] = (const char*)p.A + ((size_t)ar * p.lda + lch * 8) * 2;
-    w_src[j] = (const char*)p.W + ((size_t)wr * p.ldw + lch * 8) * 2;
-  }
-  const unsigned a_dst = lds_base + wid * PIECES * 1024;
-  const unsigned w_dst = lds_base + BM * 64 + wid * PIECES * 1024;
-
-#define RG_ISSUE(KT)                                                                        \
-  do {                                                                                      \
-    const int st_ = ((KT) & (NST - 1)) * STAGE;                                             \
-    const int kb_ = (KT)*BK * 2;                                                            \
-    _Pragma("unroll") for (int j = 0; j < PIECES; ++j) glds16(a_src[j] + kb_, a_dst + st_ + j * 1024); \
-    _Pragma("unroll") for (int j = 0; j < PIECES; ++j) glds16(w_src[j] + kb_, w_dst + st_ + j * 1024); \
-  } while (0)
-
-  f32x4_t acc[TN][TM];
-#pragma unroll
-  for (int i = 0; i < TN; ++i)
-#pragma unroll
-    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  const int frow = lane & 15, g = lane >> 4;
-  const int kc_off = ((g ^ ((-(frow >> 2)) & 3)) << 4);
-  const int x_frag = (wm * WM + frow) * 64 + kc_off;
-  const int w_frag = BM * 64 + (wn * WN + frow) * 64 + kc_off;
-  const int nk = p.K / BK;
-
-  RG_ISSUE(0);
-  if (nk > 1) RG_ISSUE(1);
-  if (nk > 2) RG_ISSUE(2);
-
-  for (int kt = 0; kt < nk; ++kt) {
-    // this wave's pieces of slice kt have landed once at most the two younger slices (2 x 4 DMAs) are outstanding
-    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();   // every wave's pieces of slice kt are in LDS; all reads of slice kt-1 are done
-    __builtin_amdgcn_sched_barrier(0);
-    if (kt + 3 < nk) RG_ISSUE(kt + 3);   // overwrites the stage read during iteration kt-1
-    const char* cur = smem + (kt & (NST - 1)) * STAGE;
-    bf16x8_t xf[TM], wf[TN];
-#pragma unroll
-    for (int j = 0; j < TM; ++j) xf[j] = *(const bf16x8_t*)(cur + x_frag + j * 16 * 64);
-#pragma unroll
-    for (int i = 0; i < TN; ++i) wf[i] = *(const bf16x8_t*)(cur + w_frag + i * 16 * 64);
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-      for (int j = 0; j < TM; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-  }
-#undef RG_ISSUE
-  __syncthreads();
-  if (p.staged_epi)
-    gemm_epilogue_lds<TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lane, wid, smem);
-  else
-    gemm_epilogue<TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lane);
-}
-
-// ---- duo variant: two co-resident 4-wave blocks per CU, each on a 256x128 tile ------------------------------
-// tools/gemm_ablate.py on the 256x256 kernel: the epilogue (bf16/fp32 stores, saved pre-activations) is 25-30 % of
-// the kernel and the matrix pipe idles through it, because the single 8-wave block of a CU is in its epilogue as a
-// whole.  Here a block is 4 waves (2x2, 128x64 per wave as before) on a 256x128 tile fed through a 3-deep ring of
-// 32-wide K slices (3 x 24 KiB = 72 KiB LDS), so TWO blocks fit a CU (2 waves/SIMD, 256 VGPRs each) and drift apart:
-// one block's epilogue, prologue and launch gap run under the other block's MFMA stream.  DMA for slice t+2 is issued
-// after the barrier of slice t and waited with a counted vmcnt (one younger slice stays in flight).  Accumulation
-// order per output element equals the other kernels' (bitwise-equal results).
-__global__ __launch_bounds__(256, 2) void gemm_nt_duo_kernel(GemmNtArgs p) {
-  constexpr int BM = 256, BN = 128, WAVES_N = 2, BK = 32;   // 3-deep stage ring
-  constexpr int WM = 128, WN = 64, TM = 8, TN = 4;
-  constexpr int A_PIECES = 4, W_PIECES = 2;   // 1-KiB pieces (16 rows x 64 B) per wave per stage
-  constexpr int STAGE = (BM + BN) * 64;       // 24 KiB
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)LDS_PTR(smem);
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid / WAVES_N, wn = wid % WAVES_N;
-  const int ntn = (p.N + BN - 1) / BN;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
-
-  const int lrow = lane >> 2, lch = (lane & 3) ^ ((-(lane >> 4)) & 3);
-  const char* a_src[A_PIECES];
-  const char* w_src[W_PIECES];
-#pragma unroll
-  for (int j = 0; j < A_PIECES; ++j) {
-    int ar = m0 + 16 * (wid * A_PIECES + j) + lrow;
-    ar = ar < p.M ? ar : p.M - 1;
-    a_src[j] = (const char*)p.A + ((size_t)ar * p.lda + lch * 8) * 2;
-  }
-#pragma unroll
-  for (int j = 0; j < W_PIECES; ++j) {
-    int wr = n0 + 16 * (wid * W_PIECES + j) + lrow;
-    wr = wr < p.N ? wr : p.N - 1;
-    w_src[j] = (const char*)p.W + ((size_t)wr * p.ldw + lch * 8) * 2;
-  }
-  const unsigned a_dst = lds_base + wid * A_PIECES * 1024;
-  const unsigned w_dst = lds_base + BM * 64 + wid * W_PIECES * 1024;
-
-#define DUO_ISSUE(ST, KT)                                                                   \
-  do {                                                                                      \
-    const int st_ = (ST)*STAGE;                                                             \
-    const int kb_ = (KT)*BK * 2;                                                            \
-    _Pragma("unroll") for (int j = 0; j < A_PIECES; ++j) glds16(a_src[j] + kb_, a_dst + st_ + j * 1024); \
-    _Pragma("unroll") for (int j = 0; j < W_PIECES; ++j) glds16(w_src[j] + kb_, w_dst + st_ + j * 1024); \
-  } while (0)
-
-  f32x4_t acc[TN][TM];
-#pragma unroll
-  for (int i = 0; i < TN; ++i)
-#pragma unroll
-    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  const int frow = lane & 15, g = lane >> 4;
-  const int kc_off = ((g ^ ((-(frow >> 2)) & 3)) << 4);
-  const int x_frag = (wm * WM + frow) * 64 + kc_off;
-  const int w_frag = BM * 64 + (wn * WN + frow) * 64 + kc_off;
-  const int nk = p.K / BK;   // even, >= 2 (K % 64 == 0)
-
-  DUO_ISSUE(0, 0);
-  DUO_ISSUE(1, 1);
-
-  int st = 0;                // stage of slice kt
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // slice kt+1 may stay in flight
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();   // slice kt is in LDS for every wave; all reads of slice kt-1 are done
-    __builtin_amdgcn_sched_barrier(0);
-    const int st2 = st == 0 ? 2 : st - 1;   // (kt + 2) % 3: the stage read during iteration kt-1
-    if (kt + 2 < nk) DUO_ISSUE(st2, kt + 2);
-    const char* cur = smem + st * STAGE;
-    bf16x8_t xf[TM], wf[TN];
-#pragma unroll
-    for (int j = 0; j < TM; ++j) xf[j] = *(const bf16x8_t*)(cur + x_frag + j * 16 * 64);
-#pragma unroll
-    for (int i = 0; i < TN; ++i) wf[i] = *(const bf16x8_t*)(cur + w_frag + i * 16 * 64);
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-      for (int j = 0; j < TM; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-    st = st == 2 ? 0 : st + 1;
-  }
-#undef DUO_ISSUE
-  __syncthreads();
-  if (p.staged_epi)
-    gemm_epilogue_lds<TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lane, wid, smem);
-  else
-    gemm_epilogue<TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lane);
-}
-
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 int launch_cfg(const GemmNtArgs& a, hipStream_t stream, int batch = 1) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
@@ -1215,12 +712,12 @@ int launch_cfg(const GemmNtArgs& a, hipStream_t stream, int batch = 1) {
   return lc2is_check_launch();
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int DBG = 0, int EPI = -1>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI = -1>
 int launch_dma(const GemmNtArgs& a, hipStream_t stream) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int STAGES = 2 * (BM + BN) * 128, PATCHES = EPI == -2 ? WAVES_M * WAVES_N * 64 * 272 : 0;   // fp32 epilogue patches overlay the stages
   constexpr int LDS = STAGES > PATCHES ? STAGES : PATCHES;
-  auto kern = gemm_nt_dma_kernel<BM, BN, WAVES_M, WAVES_N, DBG, EPI>;
+  auto kern = gemm_nt_dma_kernel<BM, BN, WAVES_M, WAVES_N, EPI>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
@@ -1229,23 +726,6 @@ int launch_dma(const GemmNtArgs& a, hipStream_t stream) {
   }
   const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
   hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(NT), LDS, stream, a);
-  return lc2is_check_launch();
-}
-
-template <int ACT>
-int launch_persist_act(const GemmNtArgs& a, hipStream_t stream) {
-  constexpr int LDS = (256 + 256) * 128 + 8 * 64 * 144;   // stage 0 | stage 1 overlaid by the eight epilogue patches (72 KiB)
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_nt_persist_kernel<ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
-        hipSuccess)
-      return LC2IS_ERR_LAUNCH;
-    attr_set = true;
-  }
-  const int ntiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
-  const int grid = ntiles < 256 ? ntiles : 256;
-  static const int stagger = getenv("LC2IS_GEMM_STAGGER") ? atoi(getenv("LC2IS_GEMM_STAGGER")) : 0;   // 10-ns ticks per phase
-  hipLaunchKernelGGL(gemm_nt_persist_kernel<ACT>, dim3(grid), dim3(512), LDS, stream, a, ntiles, stagger);
   return lc2is_check_launch();
 }
 
@@ -1282,62 +762,6 @@ int launch_persist2(const GemmNtArgs& a, hipStream_t stream) {
   }
 }
 
-int launch_persist(const GemmNtArgs& a, hipStream_t stream) {
-  switch (a.act) {
-    case LC2IS_ACT_QUICK_GELU: return launch_persist_act<LC2IS_ACT_QUICK_GELU>(a, stream);
-    case LC2IS_ACT_RELU: return launch_persist_act<LC2IS_ACT_RELU>(a, stream);
-    case LC2IS_ACT_DQUICK_GELU: return launch_persist_act<LC2IS_ACT_DQUICK_GELU>(a, stream);
-    case LC2IS_ACT_DRELU: return launch_persist_act<LC2IS_ACT_DRELU>(a, stream);
-    case LC2IS_ACT_QUICK_GELU_GRAD: return launch_persist_act<LC2IS_ACT_QUICK_GELU_GRAD>(a, stream);
-    case LC2IS_ACT_MUL_AUX: return launch_persist_act<LC2IS_ACT_MUL_AUX>(a, stream);
-    case LC2IS_ACT_GELU_ERF: return launch_persist_act<LC2IS_ACT_GELU_ERF>(a, stream);
-    case LC2IS_ACT_DGELU_ERF: return launch_persist_act<LC2IS_ACT_DGELU_ERF>(a, stream);
-    default: return launch_persist_act<LC2IS_ACT_NONE>(a, stream);
-  }
-}
-
-int launch_ring(const GemmNtArgs& a, hipStream_t stream) {
-  constexpr int LDS = 4 * (256 + 256) * 64;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_nt_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
-        hipSuccess)
-      return LC2IS_ERR_LAUNCH;
-    attr_set = true;
-  }
-  const int ntm = (a.M + 255) / 256, ntn = (a.N + 255) / 256;
-  hipLaunchKernelGGL(gemm_nt_ring_kernel, dim3(ntm * ntn), dim3(512), LDS, stream, a);
-  return lc2is_check_launch();
-}
-
-int launch_duo(const GemmNtArgs& a, hipStream_t stream) {
-  constexpr int LDS = 3 * (256 + 128) * 64;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_nt_duo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
-        hipSuccess)
-      return LC2IS_ERR_LAUNCH;
-    attr_set = true;
-  }
-  const int ntm = (a.M + 255) / 256, ntn = (a.N + 127) / 128;
-  hipLaunchKernelGGL(gemm_nt_duo_kernel, dim3(ntm * ntn), dim3(256), LDS, stream, a);
-  return lc2is_check_launch();
-}
-
-int launch_pp(const GemmNtArgs& a, hipStream_t stream) {
-  constexpr int LDS = 2 * (256 + 256) * 128;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_nt_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
-        hipSuccess)
-      return LC2IS_ERR_LAUNCH;
-    attr_set = true;
-  }
-  const int ntm = (a.M + 255) / 256, ntn = (a.N + 255) / 256;
-  hipLaunchKernelGGL(gemm_nt_pp_kernel, dim3(ntm * ntn), dim3(512), LDS, stream, a);
-  return lc2is_check_launch();
-}
-
 int launch_by_cfg(const GemmNtArgs& a_in, int cfg, hipStream_t stream) {
   GemmNtArgs a = a_in;
   const bool f32_staged = a.staged_epi == 2;
@@ -1348,45 +772,30 @@ int launch_by_cfg(const GemmNtArgs& a_in, int cfg, hipStream_t stream) {
     case 2: return launch_cfg<256, 128, 4, 2>(a, stream);
     case 3: return launch_cfg<64, 64, 2, 2>(a, stream);
     case 4:
-      if (f32_staged) return launch_dma<256, 256, 2, 4, 0, -2>(a, stream);
+      if (f32_staged) return launch_dma<256, 256, 2, 4, -2>(a, stream);
       if (!per_act) return launch_dma<256, 256, 2, 4>(a, stream);
       switch (a.act) {
-        case LC2IS_ACT_QUICK_GELU: return launch_dma<256, 256, 2, 4, 0, LC2IS_ACT_QUICK_GELU>(a, stream);
-        case LC2IS_ACT_RELU: return launch_dma<256, 256, 2, 4, 0, LC2IS_ACT_RELU>(a, stream);
-        case LC2IS_ACT_DQUICK_GELU: return launch_dma<256, 256, 2, 4, 0, LC2IS_ACT_DQUICK_GELU>(a, stream);
-        case LC2IS_ACT_DRELU: return launch_dma<256, 256, 2, 4, 0, LC2IS_ACT_DRELU>(a, stream);
-        case LC2IS_ACT_GELU_ERF: return launch_dma<256, 256, 2, 4, 0, LC2IS_ACT_GELU_ERF>(a, stream);
-        case LC2IS_ACT_DGELU_ERF: return launch_dma<256, 256, 2, 4, 0, LC2IS_ACT_DGELU_ERF>(a, stream);
-        case LC2IS_ACT_NONE: return launch_dma<256, 256, 2, 4, 0, LC2IS_ACT_NONE>(a, stream);
+        case LC2IS_ACT_QUICK_GELU: return launch_dma<256, 256, 2, 4, LC2IS_ACT_QUICK_GELU>(a, stream);
+        case LC2IS_ACT_RELU: return launch_dma<256, 256, 2, 4, LC2IS_ACT_RELU>(a, stream);
+        case LC2IS_ACT_DQUICK_GELU: return launch_dma<256, 256, 2, 4, LC2IS_ACT_DQUICK_GELU>(a, stream);
+        case LC2IS_ACT_DRELU: return launch_dma<256, 256, 2, 4, LC2IS_ACT_DRELU>(a, stream);
+        case LC2IS_ACT_GELU_ERF: return launch_dma<256, 256, 2, 4, LC2IS_ACT_GELU_ERF>(a, stream);
+        case LC2IS_ACT_DGELU_ERF: return launch_dma<256, 256, 2, 4, LC2IS_ACT_DGELU_ERF>(a, stream);
+        case LC2IS_ACT_NONE: return launch_dma<256, 256, 2, 4, LC2IS_ACT_NONE>(a, stream);
         default: return launch_dma<256, 256, 2, 4>(a, stream);   // codes 5 / 6 (experiments) keep the run-time switch
       }
-    case 5: return launch_dma<256, 128, 4, 2>(a, stream);
     case 6:
-      if (f32_staged) return launch_dma<128, 128, 2, 2, 0, -2>(a, stream);
+      if (f32_staged) return launch_dma<128, 128, 2, 2, -2>(a, stream);
       if (!per_act) return launch_dma<128, 128, 2, 2>(a, stream);
       switch (a.act) {   // the activations of the Swin / hierarchical-decoder GEMMs that land on this tile size
-        case LC2IS_ACT_RELU: return launch_dma<128, 128, 2, 2, 0, LC2IS_ACT_RELU>(a, stream);
-        case LC2IS_ACT_DRELU: return launch_dma<128, 128, 2, 2, 0, LC2IS_ACT_DRELU>(a, stream);
-        case LC2IS_ACT_GELU_ERF: return launch_dma<128, 128, 2, 2, 0, LC2IS_ACT_GELU_ERF>(a, stream);
-        case LC2IS_ACT_DGELU_ERF: return launch_dma<128, 128, 2, 2, 0, LC2IS_ACT_DGELU_ERF>(a, stream);
-        case LC2IS_ACT_NONE: return launch_dma<128, 128, 2, 2, 0, LC2IS_ACT_NONE>(a, stream);
+        case LC2IS_ACT_RELU: return launch_dma<128, 128, 2, 2, LC2IS_ACT_RELU>(a, stream);
+        case LC2IS_ACT_DRELU: return launch_dma<128, 128, 2, 2, LC2IS_ACT_DRELU>(a, stream);
+        case LC2IS_ACT_GELU_ERF: return launch_dma<128, 128, 2, 2, LC2IS_ACT_GELU_ERF>(a, stream);
+        case LC2IS_ACT_DGELU_ERF: return launch_dma<128, 128, 2, 2, LC2IS_ACT_DGELU_ERF>(a, stream);
+        case LC2IS_ACT_NONE: return launch_dma<128, 128, 2, 2, LC2IS_ACT_NONE>(a, stream);
         default: return launch_dma<128, 128, 2, 2>(a, stream);
       }
-    case 7: return launch_pp(a, stream);
-    case 8: return launch_ring(a, stream);
-    case 9: return launch_duo(a, stream);
-    case 10: return launch_dma<128, 384, 2, 4>(a, stream);
-    case 11: return launch_persist(a, stream);
-    case 12: return launch_dma<256, 256, 2, 2>(a, stream);      // 4 waves x (128x128): 2/3 of the LDS read traffic per FLOP
     case 13: return launch_persist2(a, stream);
-    case 48: return launch_dma<256, 256, 2, 2, 1>(a, stream);   // N = 768 / 2304: 3/4-size tiles, 64x96 per wave
-    // diagnostic ablations of cfg 4 (wrong results by design; tools/gemm_ablate.py only)
-    case 41: return launch_dma<256, 256, 2, 4, 1>(a, stream);
-    case 42: return launch_dma<256, 256, 2, 4, 2>(a, stream);
-    case 43: return launch_dma<256, 256, 2, 4, 3>(a, stream);
-    case 45: return launch_dma<256, 256, 2, 4, 5>(a, stream);
-    case 47: return launch_dma<256, 256, 2, 4, 7>(a, stream);
-    case 49: return launch_dma<256, 256, 2, 4, 15>(a, stream);   // cfg 47's skeleton on 32x32x16 MFMAs
     default: return LC2IS_ERR_UNSUPPORTED;
   }
 }

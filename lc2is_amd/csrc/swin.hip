@@ -9,8 +9,8 @@
 //     bf16 I/O, fp32 softmax.  Forward and backward run on the matrix cores (swin_attn_fwd_mfma_kernel: 16, and
 //     swin_attn_bwd_mfma_kernel: 40 v_mfma_f32_32x32x16_bf16 per window-head, rows padded to 64 with zeros); the bias-table
 //     gradient dS is accumulated per (head, window-chunk) in LDS in window order and written as partials that a second
-//     launch sums in chunk order (bitwise reproducible, no atomics).  The first, VALU forms (lane = query row, K / V
-//     broadcast from LDS) stay behind LC2IS_SWIN_FWD_VALU / LC2IS_SWIN_BWD_VALU: 108 vs ~45 and 636 vs 98 us per launch.
+//     launch sums in chunk order (bitwise reproducible, no atomics).  (The first, VALU forms — lane = query row, K / V
+//     broadcast from LDS — measured 108 vs ~45 and 636 vs 98 us per launch and were removed in round 3.)
 #include "common.h"
 #include "lc2is_hip.h"
 #include <cstdlib>
@@ -76,213 +76,6 @@ __device__ __forceinline__ int sw_region(int p, int extent, int ws, int shift) {
   return (p >= extent - ws) + (p >= extent - shift);
 }
 
-__device__ __forceinline__ void sw_load_row(const bf16_t* p, float* dst) {   // 32 bf16 -> 32 floats
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const i32x4_t pk = *(const i32x4_t*)(p + 8 * k);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      dst[8 * k + 2 * e] = bf16_to_f32((bf16_t)(pk[e] & 0xffff));
-      dst[8 * k + 2 * e + 1] = bf16_to_f32((bf16_t)((unsigned)pk[e] >> 16));
-    }
-  }
-}
-
-__device__ __forceinline__ void sw_store_row(bf16_t* p, const float* v) {
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    i32x4_t pk;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) pk[e] = (int)pack_bf16x2(v[8 * k + 2 * e], v[8 * k + 2 * e + 1]);
-    *(i32x4_t*)(p + 8 * k) = pk;
-  }
-}
-
-// forward: block = 4 waves, wave w handles pair (window, head) = blockIdx*4 + w
-__global__ __launch_bounds__(256) void swin_attn_fwd_kernel(SwinAttnArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int S = a.ws * a.ws;
-  const long pair = (long)blockIdx.x * 4 + wv;
-  if (pair >= (long)a.nwin * a.nH) return;   // whole wave exits (no block-wide barrier below)
-  const int win = (int)(pair / a.nH), h = (int)(pair % a.nH);
-  float* Ks = (float*)smem + (size_t)wv * 2 * SW_MAXS * SW_D;
-  float* Vs = Ks + SW_MAXS * SW_D;
-  const bool act = lane < S;
-  const size_t row = (size_t)win * S + (act ? lane : 0);
-  float q[SW_D];
-  {
-    float t[SW_D];
-    sw_load_row(a.qkv + row * a.ld + h * SW_D, q);
-    sw_load_row(a.qkv + row * a.ld + a.C + h * SW_D, t);
-    if (act) {
-#pragma unroll
-      for (int d = 0; d < SW_D; ++d) Ks[lane * SW_D + d] = t[d];
-    }
-    sw_load_row(a.qkv + row * a.ld + 2 * a.C + h * SW_D, t);
-    if (act) {
-#pragma unroll
-      for (int d = 0; d < SW_D; ++d) Vs[lane * SW_D + d] = t[d];
-    }
-  }
-  SW_LDS_SYNC();  // this wave's LDS writes have landed (single-wave producer/consumer, no block barrier)
-  // shifted-window mask: region ids in the shifted, padded frame
-  const int widx = win % a.win_per_img, wy = widx / a.nwx, wx = widx % a.nwx;
-  const int iy = (act ? lane : 0) / a.ws, ix = (act ? lane : 0) % a.ws;
-  const int rid = a.shift > 0 ? sw_region(wy * a.ws + iy, a.Hp, a.ws, a.shift) * 3 + sw_region(wx * a.ws + ix, a.Wp, a.ws, a.shift) : 0;
-  const float* brow = a.bias + ((size_t)h * S + (act ? lane : 0)) * S;
-  float m = -__builtin_inff(), l = 0.f, o[SW_D];
-#pragma unroll
-  for (int d = 0; d < SW_D; ++d) o[d] = 0.f;
-  for (int j = 0; j < S; ++j) {
-    const float* kj = Ks + j * SW_D;
-    float s = 0.f;
-#pragma unroll
-    for (int d = 0; d < SW_D; ++d) s += q[d] * kj[d];
-    s = s * a.scale + brow[j];
-    if (a.shift > 0) {
-      const int rj = sw_region(wy * a.ws + j / a.ws, a.Hp, a.ws, a.shift) * 3 + sw_region(wx * a.ws + j % a.ws, a.Wp, a.ws, a.shift);
-      if (rj != rid) s += -100.0f;
-    }
-    const float mn = fmaxf(m, s);
-    const float corr = __expf(m - mn), p = __expf(s - mn);
-    l = l * corr + p;
-    const float* vj = Vs + j * SW_D;
-#pragma unroll
-    for (int d = 0; d < SW_D; ++d) o[d] = o[d] * corr + p * vj[d];
-    m = mn;
-  }
-  if (act) {
-    const float inv = 1.0f / l;
-#pragma unroll
-    for (int d = 0; d < SW_D; ++d) o[d] *= inv;
-    sw_store_row(a.out + row * a.ldo + h * SW_D, o);
-    if (a.lse) a.lse[((size_t)win * a.nH + h) * S + lane] = m + __logf(l);
-  }
-}
-
-// backward: one wave per block; block (h, chunk) walks the windows of its chunk in order.
-// LDS per block (22.5 KiB at S = 49, so seven blocks share a CU): two [S][32] fp32 tiles — K,V while the lanes are query
-// rows (pass A: dQ), then overwritten by Q,dO while the lanes are key rows (pass B: dK, dV, with the logits recomputed
-// rather than a [S][S] P / dS matrix kept) — plus the [S][S] bias-gradient accumulator and the per-row lse / delta.
-__global__ __launch_bounds__(64) void swin_attn_bwd_kernel(SwinAttnArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x;
-  const int S = a.ws * a.ws;
-  const int h = blockIdx.x % a.nH, chunk = blockIdx.x / a.nH;
-  float* T0 = (float*)smem;                    // [S][32]: K, then Q
-  float* T1 = T0 + S * SW_D;                   // [S][32]: V, then dO
-  float* Acc = T1 + S * SW_D;                  // [S][S]
-  float* Ls = Acc + S * S;                     // [S] lse
-  float* Dl = Ls + S;                          // [S] delta = dO . O
-  const bool act = lane < S;
-  for (int idx = lane; idx < S * S; idx += 64) Acc[idx] = 0.f;
-  const int w_begin = chunk * a.chunk;
-  int w_end = w_begin + a.chunk;
-  if (w_end > a.nwin) w_end = a.nwin;
-  const int li = act ? lane : 0;
-  const int iy = li / a.ws, ix = li % a.ws;
-  for (int win = w_begin; win < w_end; ++win) {
-    const size_t row = (size_t)win * S + li;
-    float q[SW_D], dO[SW_D], kr[SW_D], vr[SW_D];
-    sw_load_row(a.qkv + row * a.ld + h * SW_D, q);
-    sw_load_row(a.dout + row * a.lddo + h * SW_D, dO);
-    sw_load_row(a.qkv + row * a.ld + a.C + h * SW_D, kr);
-    sw_load_row(a.qkv + row * a.ld + 2 * a.C + h * SW_D, vr);
-    float delta = 0.f;
-    {
-      float ov[SW_D];
-      sw_load_row(a.o + row * a.ld_o + h * SW_D, ov);
-#pragma unroll
-      for (int d = 0; d < SW_D; ++d) delta += dO[d] * ov[d];
-    }
-    const float lse = a.lse[((size_t)win * a.nH + h) * S + li];
-    SW_LDS_SYNC();   // the previous window's pass B has finished with the tiles
-    if (act) {
-#pragma unroll
-      for (int d = 0; d < SW_D; ++d) { T0[lane * SW_D + d] = kr[d]; T1[lane * SW_D + d] = vr[d]; }
-      Ls[lane] = lse;
-      Dl[lane] = delta;
-    }
-    SW_LDS_SYNC();
-    const int widx = win % a.win_per_img, wy = widx / a.nwx, wx = widx % a.nwx;
-    const int rid = a.shift > 0 ? sw_region(wy * a.ws + iy, a.Hp, a.ws, a.shift) * 3 + sw_region(wx * a.ws + ix, a.Wp, a.ws, a.shift) : 0;
-    // ---- pass A: lane = query row i ----
-    {
-      const float* brow = a.bias + ((size_t)h * S + li) * S;
-      float dq[SW_D];
-#pragma unroll
-      for (int d = 0; d < SW_D; ++d) dq[d] = 0.f;
-      for (int j = 0; j < S; ++j) {
-        const float* kj = T0 + j * SW_D;
-        const float* vj = T1 + j * SW_D;
-        float s = 0.f, dp = 0.f;
-#pragma unroll
-        for (int d = 0; d < SW_D; ++d) { s += q[d] * kj[d]; dp += dO[d] * vj[d]; }
-        s = s * a.scale + brow[j];
-        if (a.shift > 0) {
-          const int rj = sw_region(wy * a.ws + j / a.ws, a.Hp, a.ws, a.shift) * 3 + sw_region(wx * a.ws + j % a.ws, a.Wp, a.ws, a.shift);
-          if (rj != rid) s += -100.0f;
-        }
-        const float dss = __expf(s - lse) * (dp - delta) * a.scale;
-#pragma unroll
-        for (int d = 0; d < SW_D; ++d) dq[d] += dss * kj[d];
-      }
-      if (act) sw_store_row(a.dqkv + row * a.lddq + h * SW_D, dq);
-    }
-    SW_LDS_SYNC();   // every lane is done reading K, V
-    if (act) {
-#pragma unroll
-      for (int d = 0; d < SW_D; ++d) { T0[lane * SW_D + d] = q[d]; T1[lane * SW_D + d] = dO[d]; }
-    }
-    SW_LDS_SYNC();
-    // ---- pass B: lane = key row j (own k, v rows are still in registers) ----
-    {
-      float dk[SW_D], dv[SW_D];
-#pragma unroll
-      for (int d = 0; d < SW_D; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
-      const float* bcol = a.bias + (size_t)h * S * S + li;
-      for (int i = 0; i < S; ++i) {
-        const float* qi = T0 + i * SW_D;
-        const float* di = T1 + i * SW_D;
-        float s = 0.f, dp = 0.f;
-#pragma unroll
-        for (int d = 0; d < SW_D; ++d) { s += qi[d] * kr[d]; dp += di[d] * vr[d]; }
-        s = s * a.scale + bcol[(size_t)i * S];
-        if (a.shift > 0) {
-          const int ri = sw_region(wy * a.ws + i / a.ws, a.Hp, a.ws, a.shift) * 3 + sw_region(wx * a.ws + i % a.ws, a.Wp, a.ws, a.shift);
-          if (ri != rid) s += -100.0f;   // rid: region of this lane's own token (here the key)
-        }
-        const float p = __expf(s - Ls[i]);
-        const float ds = p * (dp - Dl[i]);
-        if (act) Acc[i * S + lane] += ds;
-        const float dss = ds * a.scale;
-#pragma unroll
-        for (int d = 0; d < SW_D; ++d) { dk[d] += dss * qi[d]; dv[d] += p * di[d]; }
-      }
-      if (act) {
-        sw_store_row(a.dqkv + row * a.lddq + a.C + h * SW_D, dk);
-        sw_store_row(a.dqkv + row * a.lddq + 2 * a.C + h * SW_D, dv);
-      }
-    }
-  }
-  SW_LDS_SYNC();
-  if (a.dbias_part) {
-    float* dst = a.dbias_part + ((size_t)chunk * a.nH + h) * S * S;
-    for (int idx = lane; idx < S * S; idx += 64) dst[idx] = Acc[idx];
-  }
-}
-
-// ---- backward on the matrix cores ------------------------------------------------------------------------------------
-// Same block structure (one wave per block, block (h, chunk) walks its windows in order, dS accumulated per block in LDS), but
-// the five products of a (window, head) are 40 v_mfma_f32_32x32x16_bf16 instead of ~10^4 VALU FMAs fed by LDS broadcasts:
-//   S[q][key] = Q.K^T and dP[q][key] = dO.V^T   with the row fragments loaded straight from global memory (rows padded to 64
-//               with zeros), result tiles "key on the lane, query rows in the registers";
-//   P = exp(S*scale + bias (+ mask) - lse), dS = P o (dP - delta) elementwise on those registers; dS also goes to LDS (bf16);
-//   dV[key][d] = P^T.dO and dK[key][d] = dS^T.Q  take the P / dS accumulator registers directly as the MFMA A operand
-//               (accumulator-as-operand: lane = key = A row, registers = the 16 queries of a k step, in the order
-//               q0+{0..3}, q0+8+{0..3} with q0 = 32tq + 16s2 + 4hh) against dO^T / Q^T images in LDS read in that same order;
-//   dQ[q][d]   = dS.K from the dS image (rows q) and the K^T image.
 // LDS images are bf16 with a 144-byte row pitch (128 B of data + 16: conflict-free ds_read_b128 over 32 rows).
 constexpr int SWM_P = 144;
 
@@ -663,19 +456,6 @@ extern "C" int lc2is_swin_attn_fwd(const void* qkv, int ld, void* out, int ldo, 
   a.qkv = (const bf16_t*)qkv; a.ld = ld; a.out = (bf16_t*)out; a.ldo = ldo; a.lse = lse; a.bias = bias;
   a.nwin = nwin; a.win_per_img = win_per_img; a.nwx = nwx; a.Hp = Hp; a.Wp = Wp; a.ws = ws; a.shift = shift; a.nH = nH;
   a.C = C; a.scale = scale;
-  const long pairs = (long)nwin * nH;
-  const int lds = 4 * 2 * SW_MAXS * SW_D * (int)sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)swin_attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-      return LC2IS_ERR_LAUNCH;
-    attr_set = true;
-  }
-  static const bool use_valu = getenv("LC2IS_SWIN_FWD_VALU") && atoi(getenv("LC2IS_SWIN_FWD_VALU")) != 0;   // A/B switch
-  if (use_valu) {
-    hipLaunchKernelGGL(swin_attn_fwd_kernel, dim3((int)((pairs + 3) / 4)), dim3(256), lds, stream, a);
-    return lc2is_check_launch();
-  }
   // matrix-core form: single-wave blocks, ~14 KB of LDS each (8 resident per CU), one round of them
   int nchunk = 2048 / nH > 0 ? 2048 / nH : 1;
   if (nchunk > nwin) nchunk = nwin;
@@ -703,9 +483,8 @@ extern "C" int lc2is_swin_attn_bwd(const void* qkv, int ld, const void* o, int l
   if (rc) return rc;
   if (ld < 3 * C || lddq < 3 * C || ld_o < C || lddo < C || ld % 8 || lddq % 8 || ld_o % 8 || lddo % 8) return LC2IS_ERR_SHAPE;
   if (dbias && (!workspace || workspace_bytes < lc2is_swin_attn_bwd_workspace_bytes(nwin, ws, nH))) return LC2IS_ERR_WORKSPACE;
-  static const bool use_valu = getenv("LC2IS_SWIN_BWD_VALU") && atoi(getenv("LC2IS_SWIN_BWD_VALU")) != 0;   // A/B switch
   int nchunk = sw_chunks(nwin, nH);
-  if (!use_valu) {   // the MFMA form holds 34 KB of LDS and ~300 registers: four single-wave blocks per CU, one round of them
+  {   // the kernel holds 34 KB of LDS and ~300 registers: four single-wave blocks per CU, one round of them
     const int c4 = 1024 / nH > 0 ? 1024 / nH : 1;
     if (nchunk > c4) nchunk = c4;
   }
@@ -716,20 +495,15 @@ extern "C" int lc2is_swin_attn_bwd(const void* qkv, int ld, const void* o, int l
   a.nwin = nwin; a.win_per_img = win_per_img; a.nwx = nwx; a.Hp = Hp; a.Wp = Wp; a.ws = ws; a.shift = shift; a.nH = nH;
   a.C = C; a.scale = scale; a.chunk = (nwin + nchunk - 1) / nchunk;
   const int S_ = ws * ws;
-  const int lds = (2 * S_ * SW_D + S_ * S_ + 2 * S_) * (int)sizeof(float);
   const int lds_mfma = (3 * 32 + 64) * SWM_P + (64 + 128 + 64) * 4 + (S_ * S_ + 64) * (int)sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)swin_attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
-        hipFuncSetAttribute((const void*)swin_attn_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)swin_attn_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
       return LC2IS_ERR_LAUNCH;
     attr_set = true;
   }
   const int nchunk_eff = (nwin + a.chunk - 1) / a.chunk;
-  if (use_valu)
-    hipLaunchKernelGGL(swin_attn_bwd_kernel, dim3(nchunk_eff * nH), dim3(64), lds, stream, a);
-  else
-    hipLaunchKernelGGL(swin_attn_bwd_mfma_kernel, dim3(nchunk_eff * nH), dim3(64), lds_mfma, stream, a);
+  hipLaunchKernelGGL(swin_attn_bwd_mfma_kernel, dim3(nchunk_eff * nH), dim3(64), lds_mfma, stream, a);
   rc = lc2is_check_launch();
   if (rc || !dbias) return rc;
   const size_t n = (size_t)nH * ws * ws * ws * ws;

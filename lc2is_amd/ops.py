@@ -128,9 +128,6 @@ def _out(spec, shape, dtype, dev):
     return spec
 
 
-import os as _os
-# experiment hook: LC2IS_GEMM_CFG="act=6,resid=4,plain=4" forces tile configs per epilogue class (large M only)
-_FORCE_CFG = {k: int(v) for k, v in (kv.split("=") for kv in _os.environ.get("LC2IS_GEMM_CFG", "").split(",") if kv)}
 
 _ws_cache: dict = {}
 
@@ -166,8 +163,6 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None, 
     of = _out(out_f32, (M, N), torch.float32, dev)
     ao = _out(aux_out, (M, N), torch.bfloat16, dev)
     _chk(ob, torch.bfloat16, "out_bf16"); _chk(of, torch.float32, "out_f32"); _chk(ao, torch.bfloat16, "aux_out")
-    if tile_cfg == 0 and _FORCE_CFG:
-        tile_cfg = _FORCE_CFG.get("act" if act else ("resid" if resid is not None else "plain"), 0) if M >= 4096 else 0
     rc = _fn("lc2is_gemm_nt_bf16")(_ptr(a), _ld(a), _ptr(w), _ld(w), _ptr(bias), _ptr(resid), _ld(resid),
                                    _ptr(aux_in), _ld(aux_in), _ptr(ob), _ld(ob), _ptr(of), _ld(of), _ptr(ao),
                                    _ld(ao), M, N, K, act, tile_cfg, _stream())

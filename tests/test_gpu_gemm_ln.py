@@ -16,9 +16,7 @@ def _rel(a, b):
 @pytest.mark.parametrize("M,N,K,cfg", [
     (300, 192, 128, 1), (300, 192, 128, 2), (300, 192, 128, 3), (1025, 768, 768, 0), (4100, 2304, 768, 0),
     (129, 152, 512, 0), (77, 64, 64, 3), (2050, 768, 3072, 2), (2050, 768, 3072, 4), (300, 192, 128, 4),
-    (1025, 2304, 768, 5), (300, 192, 128, 5), (515, 384, 192, 6), (4100, 768, 768, 4),
-    (2050, 768, 3072, 7), (300, 192, 128, 7), (4100, 768, 768, 7), (1025, 2304, 64, 7),
-    (2050, 768, 3072, 8), (300, 192, 128, 8), (4100, 768, 768, 8), (1025, 2304, 64, 8),
+    (515, 384, 192, 6), (4100, 768, 768, 4),
 ])
 def test_gemm_nt_plain(dev, M, N, K, cfg):
     from lc2is_amd import ops
@@ -75,7 +73,7 @@ def test_gemm_nt_asymmetric_identity(dev):
     assert torch.equal(of, w.float().T.contiguous())
 
 
-@pytest.mark.parametrize("cfg", [0, 4, 5, 6, 7, 8, 10])
+@pytest.mark.parametrize("cfg", [0, 4, 6])
 @pytest.mark.parametrize("act", ["quick_gelu", "relu"])
 def test_gemm_nt_activation_and_backward_epilogue(dev, act, cfg):
     from lc2is_amd import ops
@@ -159,10 +157,10 @@ def test_gemm_nt_auto_plan_ragged_rows(dev, N, K):
     assert _rel(outs[0][1][-40:], ref * sg + resid[-40:].double()) < 1e-5      # the peeled rows themselves
 
 
-@pytest.mark.parametrize("cfg", [0, 3, 4, 9])
+@pytest.mark.parametrize("cfg", [0, 3, 4])
 def test_gemm_nt_gelu_derivative_pair(dev, cfg):
     """Codes 5/6: the forward epilogue saves quick_gelu'(z) (bf16) next to the activation; the backward epilogue
-    multiplies by it.  cfg 3 = direct epilogue, 4/9 = LDS-staged epilogue."""
+    multiplies by it.  cfg 3 = direct epilogue, 4 = LDS-staged epilogue."""
     from lc2is_amd import ops
     g = torch.Generator(device="cpu").manual_seed(6)
     M, N, K = 515, 384, 192
@@ -299,20 +297,24 @@ def test_layernorm_bwd_deferred_param_grads_are_bitwise_equal(dev):
     assert ((g1[0] - ref).norm() / ref.norm()).item() < 1e-3
 
 
-def test_gemm_nt_pingpong_is_bitwise_equal_to_simple_pipeline(dev):
-    """The ping-pong kernel (hand-placed waits, staggered wave groups) accumulates in the same order as the
-    simple LDS-DMA kernel: any race in its schedule shows up as a bit difference.  Several shapes x repeats."""
+def test_gemm_nt_default_plan_matches_single_kernel_on_the_step_shapes(dev):
+    """The default dispatch at the headline row count (32 x 1025 = 128 row tiles + 32 ragged rows: persistent form for the
+    bf16 outputs, ragged rows peeled into a small-tile launch for the fp32 ones) against the one-kernel 256x256 plan, for
+    one layer's GEMM shapes."""
     from lc2is_amd import ops
-    g = torch.Generator(device="cpu").manual_seed(77)
-    for (M, N, K) in [(32800, 768, 768), (8200, 3072, 768), (4100, 768, 3072), (1025, 2304, 768), (257, 256, 128)]:
+    g = torch.Generator(device="cpu").manual_seed(3)
+    M = 32 * 1025
+    for (N, K) in [(2304, 768), (768, 768), (768, 2304)]:
         a = _bf(torch.randn(M, K, generator=g)).to(dev)
         w = _bf(torch.randn(N, K, generator=g) * 0.05).to(dev)
         bias = torch.randn(N, generator=g).to(dev)
-        ref, reff, _ = ops.gemm_nt(a, w, bias, out_bf16=True, out_f32=True, tile_cfg=4)
-        for cfg in (7, 8):
-            for _ in range(5):
-                ob, of, _ = ops.gemm_nt(a, w, bias, out_bf16=True, out_f32=True, tile_cfg=cfg)
-                assert torch.equal(of, reff) and torch.equal(ob, ref), (M, N, K, cfg)
+        o0, _, _ = ops.gemm_nt(a, w, bias)
+        o4, _, _ = ops.gemm_nt(a, w, bias, tile_cfg=4)
+        assert torch.equal(o0, o4), (N, K)
+        resid = torch.randn(M, N, generator=g).to(dev)
+        _, f0, _ = ops.gemm_nt(a, w, bias, resid=resid, out_bf16=None, out_f32=True)
+        _, f4, _ = ops.gemm_nt(a, w, bias, resid=resid, out_bf16=None, out_f32=True, tile_cfg=4)
+        assert torch.equal(f0, f4), (N, K)
 
 
 def test_gemm_tn_grouped(dev):
