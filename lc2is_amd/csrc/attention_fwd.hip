@@ -17,6 +17,7 @@
 // registers) into a ring of swizzled images (attn_common.h) that both kinds of read take without bank conflicts.
 // Masks (key tail, key padding, causal) are applied per score, only in tiles that need one.
 #include "attn_common.h"
+#include "attn_tail.h"
 #include "lc2is_hip.h"
 #include <cstdlib>
 
@@ -33,6 +34,8 @@ struct AttnFwdArgs {
   float scale_log2;     // softmax scale * log2(e)
   int causal;
   DropCfg drop;         // attention-probability dropout (DROP instantiations only)
+  int nqb;              // 128-query blocks per (batch, head) on the tiled path; with `tail` the last row (Sq = 128 nqb + 1) goes
+  int tail;             // to one vector-arithmetic block per (batch, head) at the end of the grid (attn_tail.h)
 };
 
 // Structure.  Measured on MI355X at S = 1025, D = 64 (rocprofv3 SQ counters — tools/pmc_attn.sh —, s_memtime phase stamps of a diagnostic build
@@ -74,8 +77,16 @@ __global__ __launch_bounds__(256, (D == 64) ? 3 : 2) void attn_fwd_kernel(AttnFw
   const int hh = lane >> 5, l31 = lane & 31;
   // 1-D grid, XCD-aware: the query blocks of one (batch, head) — which stream the same K / V — are neighbours in the tile
   // order, and xcd_remap gives every XCD (its own L2) one contiguous chunk of that order
-  const int nqb = (p.Sq + QB - 1) / QB;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  // (the tail blocks come FIRST in the grid: short, latency-bound blocks that finish under the first round of tiled blocks; at the
+  //  end of the grid they ran alone after the last round — measured slower than the padded ninth block they replace)
+  const int nqb = p.nqb, nmain = nqb * p.H * p.B, ntail = p.tail ? p.H * p.B : 0;
+  if ((int)blockIdx.x < ntail) {   // block-uniform; no barrier has been executed
+    if constexpr (D == 64 && !DROP)
+      attn_fwd_tail_row(p.Q, p.ldq, p.K, p.ldk, p.V, p.ldv, p.O, p.ldo, p.lse2, p.H, p.Sq, p.Sk, p.scale_log2, blockIdx.x / p.H,
+                        blockIdx.x % p.H, smem);
+    return;
+  }
+  const int tile = xcd_remap(blockIdx.x - ntail, nmain);
   const int bx = tile % nqb, head = (tile / nqb) % p.H, b = tile / (nqb * p.H);
   const int q0 = bx * QB + wid * 32;                  // first query of this wave
   const int qrow = q0 + l31;
@@ -251,16 +262,18 @@ __global__ __launch_bounds__(256, (D == 64) ? 3 : 2) void attn_fwd_kernel(AttnFw
     auto step = [&](int kt, auto so_c, auto son_c, auto sreq_c, auto masked_c, auto more_c) __attribute__((always_inline)) {
       const int so = so_c, son = son_c, sreq = sreq_c;
       const bool more = decltype(more_c)::value || kt + 1 < nkt;
+      // a ragged last tile with at most 32 keys (S = 64 n + 1): its second half holds nothing (wave-uniform; never on interior tiles)
+      const bool h1 = !decltype(masked_c)::value || kt * 64 + 32 < p.Sk;
       if (wave_active) {
         frame(sa, kt, 0, masked_c);
-        issue_s(so, 1, sb);                   // second half of this tile, under the exp2 / P.V of the first
+        if (h1) issue_s(so, 1, sb);           // second half of this tile, under the exp2 / P.V of the first
         finish(sa, so, kt, 0);
       }
       if (more) {
         land();
         if (kt + 2 < nkt) request(kt + 2, sreq);
       }
-      if (wave_active) {
+      if (wave_active && h1) {
         frame(sb, kt, 1, masked_c);
         if (more) issue_s(son, 0, sa);        // first half of the next tile, under the exp2 / P.V of this one
         finish(sb, so, kt, 1);
@@ -285,13 +298,16 @@ __global__ __launch_bounds__(256, (D == 64) ? 3 : 2) void attn_fwd_kernel(AttnFw
       const int so = so_c, son = son_c;
       land();
       if (kt + 1 < nkt) request(kt + 1, son);
+      const bool h1 = !decltype(masked_c)::value || kt * 64 + 32 < p.Sk;
       if (wave_active) {
         issue_s(so, 0, sa);
         frame(sa, kt, 0, masked_c);
-        issue_s(so, 1, sb);
+        if (h1) issue_s(so, 1, sb);
         finish(sa, so, kt, 0);
-        frame(sb, kt, 1, masked_c);
-        finish(sb, so, kt, 1);
+        if (h1) {
+          frame(sb, kt, 1, masked_c);
+          finish(sb, so, kt, 1);
+        }
       }
     };
     const std::true_type yes;
@@ -354,7 +370,7 @@ int launch_attn_fwd(const AttnFwdArgs& a, hipStream_t stream) {
       return LC2IS_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(((a.Sq + 127) / 128) * a.H * a.B), dim3(256), LDS, stream, a);
+  hipLaunchKernelGGL(kern, dim3((a.nqb + a.tail) * a.H * a.B), dim3(256), LDS, stream, a);
   return lc2is_check_launch();
 }
 
@@ -375,7 +391,12 @@ static int attention_fwd_impl(const void* Q, int ldq, const void* K, int ldk, co
       (double)B * (Sk + 64) * ldv * 2.0 >= 2147483648.0)
     return LC2IS_ERR_UNSUPPORTED;
   AttnFwdArgs a{(const bf16_t*)Q, ldq, (const bf16_t*)K, ldk, (const bf16_t*)V, ldv, (bf16_t*)O, ldo, lse2,
-                kbias, B, H, Sq, Sk, scale * 1.44269504088896341f, causal, make_drop_cfg(p_drop, seed)};
+                kbias, B, H, Sq, Sk, scale * 1.44269504088896341f, causal, make_drop_cfg(p_drop, seed), (Sq + 127) / 128, 0};
+  // the ragged last row of S = 128 n + 1 (ViT: 1025 tokens) leaves the tiled path (attn_tail.h)
+  if (D == TAIL_D && !causal && !kbias && !a.drop.thr && Sq > 128 && Sq % 128 == 1 && Sk <= 256 * TAIL_MAX_PER_THREAD) {
+    a.nqb = Sq / 128;
+    a.tail = 1;
+  }
   if (a.drop.thr) {
     if ((double)B * H * Sq >= 4294967296.0) return LC2IS_ERR_UNSUPPORTED;   // 32-bit row coordinate of the RNG
     switch (D) {
