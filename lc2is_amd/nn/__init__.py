@@ -7,12 +7,13 @@ from .hier import (CrossABlock, FTNBlock, FTNDecoder, HierarchicalCrossA, Hierar
                    SRTransformerCrossA, SRTransformerDecoder, SRTransformerSelfA)
 from .loss import AuxiliaryLoss, ContrastiveLoss, CrossEntropyLoss, NPairLoss
 from .model import BaseModelWithText, ContrastiveModel, TextToPatch
+from .compose import DenseClip, PromptFTN
 from .score import ScoreMapTail
 from . import ftn  # model/ftn.py's Decoder / Transformer keep their (generic) names inside this submodule
 from .swin import SWIN_B, SWIN_S, SWIN_T, SwinArch, SwinTransformer
 
 __all__ = ["HipModule", "ParamArena", "ClipArch", "ImageEncoderCLIP", "ImageEncoderCLIPFull", "TextEncoderCLIP",
            "TextEncoderCLIPPooler", "DecoderBlock", "DecoderLayer", "PromptDecoder", "PromptLayer", "AuxiliaryLoss", "ContrastiveLoss", "CrossEntropyLoss", "NPairLoss",
-           "BaseModelWithText", "ContrastiveModel", "TextToPatch", "ScoreMapTail", "CrossABlock", "FTNBlock", "FTNDecoder", "HierarchicalCrossA",
+           "BaseModelWithText", "ContrastiveModel", "TextToPatch", "PromptFTN", "DenseClip", "ScoreMapTail", "CrossABlock", "FTNBlock", "FTNDecoder", "HierarchicalCrossA",
            "HierarchicalSelfA", "SelfABlock", "SRTransformerCrossA", "SRTransformerDecoder", "SRTransformerSelfA", "VIT_B16", "VIT_L14", "TEXT_B", "TEXT_L", "SwinTransformer", "SwinArch",
            "SWIN_T", "SWIN_S", "SWIN_B", "ftn"]

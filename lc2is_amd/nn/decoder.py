@@ -73,6 +73,29 @@ class DecoderLayer(nn.Module):
         self.norm3 = nn.LayerNorm(d_model, eps=layer_norm_eps, bias=bias)
         if device is not None:
             self.to(device)
+        # d_kv == d_model: torch's MultiheadAttention keeps ONE packed ``multihead_attn.in_proj_weight`` [3C, C] instead of the
+        # three q / k / v matrices (torch:nn/modules/activation.py `_qkv_same_embed_dim`), so that is the key a reference
+        # checkpoint holds (DenseClip's prompt layers, model/model.py:119).  The parameters stay separate here; the key is
+        # split on load and merged on save.
+        self._register_load_state_dict_pre_hook(self._split_packed_cross_attn)
+        self._register_state_dict_hook(self._merge_packed_cross_attn)
+
+    def _split_packed_cross_attn(self, state_dict, prefix, *args):
+        k = prefix + "multihead_attn.in_proj_weight"
+        if self.d_kv == self.d_model and k in state_dict:
+            w = state_dict.pop(k)
+            C = self.d_model
+            for i, name in enumerate(("q_proj_weight", "k_proj_weight", "v_proj_weight")):
+                state_dict[prefix + "multihead_attn." + name] = w[i * C:(i + 1) * C]
+
+    @staticmethod
+    def _merge_packed_cross_attn(module, state_dict, prefix, local_metadata):
+        if module.d_kv != module.d_model:
+            return
+        keys = [prefix + "multihead_attn." + n for n in ("q_proj_weight", "k_proj_weight", "v_proj_weight")]
+        if all(k in state_dict for k in keys):
+            packed = torch.cat([state_dict.pop(k) for k in keys], dim=0)
+            state_dict[prefix + "multihead_attn.in_proj_weight"] = packed
 
 
 def _layer_shadows(layer: DecoderLayer, device):

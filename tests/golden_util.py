@@ -84,3 +84,33 @@ def swin_droppath_inputs(seed: int = 63, B: int = 4):
     keeps = (torch.rand(8, B, generator=g) >= 0.4).float()
     douts = [torch.randn(B, n, c, generator=g) * 0.2 for n, c in ((1936, 32), (484, 64), (121, 128), (36, 256))]
     return x, keeps, douts
+
+
+def _prompt_ids(g, K: int, L: int = 8, vocab_hi: int = 500, bos: int = 510, eos: int = 511):
+    """K prompts: BOS, 3-5 random tokens, EOS, EOS padding (mask 0 on the padding) — the reference's tokenizer layout."""
+    ids = torch.full((K, L), eos, dtype=torch.int64)
+    mask = torch.zeros(K, L, dtype=torch.int64)
+    for k in range(K):
+        n = 3 + (k % 3)
+        ids[k, 0] = bos
+        ids[k, 1:1 + n] = torch.randint(1, vocab_hi, (n,), generator=g)
+        mask[k, :n + 2] = 1
+    return ids, mask
+
+
+def prompt_ftn_inputs(seed: int, K: int = 6):
+    """One 512 x 512 image (the 128 x 128 token grid PromptFTN hard-codes), K prompts, labels over the K classes."""
+    g = torch.Generator().manual_seed(seed)
+    ids, mask = _prompt_ids(g, K)
+    inputs = dict(pixel_values=torch.randn(1, 3, 512, 512, generator=g), input_ids=ids, attention_mask=mask)
+    labels = torch.randint(0, K, (1, 512, 512), generator=g)
+    return inputs, labels
+
+
+def dense_clip_inputs(seed: int, B: int = 2, K: int = 5):
+    g = torch.Generator().manual_seed(seed)
+    ids, mask = _prompt_ids(g, K)
+    inputs = dict(pixel_values=torch.randn(B, 3, 64, 64, generator=g), input_ids=ids, attention_mask=mask)
+    ds = torch.randn(B, K, 4, 4, generator=g)
+    do = torch.randn(B, 17, 256, generator=g) * 0.1
+    return inputs, ds, do

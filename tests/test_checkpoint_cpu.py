@@ -78,3 +78,21 @@ def test_dropout_rng_follows_torch_seed_and_travels_with_the_checkpoint(tmp_path
     C.load_checkpoint(m, f)
     assert [DropoutRng.next_seed() for _ in range(2)] == nxt
     assert isinstance(torch.load(f, weights_only=True), dict)                   # still the reference's format
+
+
+def test_packed_cross_attention_key_of_equal_width_layers_roundtrips():
+    """d_kv == d_model: torch's MultiheadAttention (hence a reference checkpoint) holds ONE ``multihead_attn.in_proj_weight``;
+    the drop-in keeps q / k / v apart and splits / merges the key on load / save (DenseClip's prompt layers)."""
+    layer = N.PromptLayer(d_model=128, d_kv=128, nhead=2, dim_feedforward=64, batch_first=True)
+    dec = N.PromptDecoder(layer, num_layers=2)
+    sd = dec.state_dict()
+    assert "layers.0.multihead_attn.in_proj_weight" in sd and "layers.0.multihead_attn.q_proj_weight" not in sd
+    assert tuple(sd["layers.0.multihead_attn.in_proj_weight"].shape) == (384, 128)
+    ref = {k: torch.randn_like(v) for k, v in sd.items()}
+    res = dec.load_state_dict(ref, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    ca = dec.layers[1].multihead_attn
+    assert torch.equal(torch.cat([ca.q_proj_weight, ca.k_proj_weight, ca.v_proj_weight], 0), ref["layers.1.multihead_attn.in_proj_weight"])
+    # unequal widths keep the three separate keys
+    sd2 = N.PromptDecoder(N.PromptLayer(d_model=128, d_kv=256, nhead=2, dim_feedforward=64, batch_first=True), 1).state_dict()
+    assert "layers.0.multihead_attn.k_proj_weight" in sd2 and "layers.0.multihead_attn.in_proj_weight" not in sd2

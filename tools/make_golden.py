@@ -563,6 +563,124 @@ def make_dropout(R):
 
 
 
+
+def make_prompt_ftn(R):
+    """PromptFTN.forward (model/model.py:186-214) END TO END through the reference's own classes: a config-built tiny Swin
+    (embed 32, depths 1-1-1-1, window 7: the 512 x 512 input gives the hard-coded 128 x 128 token grid and stage widths
+    32/64/128/256), a config-built 1-layer CLIP text tower of width 512 behind the reference's TextEncoderCLIPPooler (frozen as
+    in its constructor), the reference's PromptDecoder(PromptLayer(512, 256, 8, batch_first=True), 2) and FTNDecoder([32,64,128,
+    256], 512), both with dropout 0 so that the TRAINING forward/backward is reproducible (the eval forward of the default
+    dropout-0.1 construction gives the same numbers).  Only PromptFTN.__init__ is bypassed (it names hub checkpoints).
+    Kept: the score map on a stride-8 grid, CE(score_map, labels), and selected gradients."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    from golden_util import make_weights, prompt_ftn_inputs
+    from transformers import SwinConfig, SwinModel
+    for cls in (R["rdec"].SRTransformerDecoder,):
+        _patch_sr_is_causal(cls)
+    torch.manual_seed(71)
+    m = _bare(R["rmodel"].PromptFTN)
+    te = _bare(R["renc"].TextEncoderCLIPPooler)
+    te.patch_size = 16
+    te.enc = R["CLIPTextModel"](R["CLIPTextConfig"](vocab_size=512, hidden_size=512, intermediate_size=128, num_hidden_layers=1,
+                                                    num_attention_heads=8, max_position_embeddings=16, eos_token_id=511,
+                                                    bos_token_id=510, pad_token_id=511))
+    m.textual_encoder = te
+    for prm in m.textual_encoder.parameters():
+        prm.requires_grad = False
+    ve = _bare(R["renc"].SwinTransformer)
+    cfg = SwinConfig(image_size=512, patch_size=4, embed_dim=32, depths=[1, 1, 1, 1], num_heads=[1, 2, 4, 8], window_size=7,
+                     drop_path_rate=0.0)
+    cfg._attn_implementation = "eager"
+    ve.encoder = SwinModel(cfg)
+    m.visual_encoder = ve
+    m.prompt_decoder = R["rdec"].PromptDecoder(R["rdec"].PromptLayer(d_model=512, d_kv=256, nhead=8, dropout=0.0, batch_first=True),
+                                               num_layers=2)
+    m.decoder = R["rdec"].FTNDecoder(in_dims=[32, 64, 128, 256], dim=512, dropout=0.0)
+    named = dict(m.named_parameters())
+    shapes = {k: list(v.shape) for k, v in named.items()}
+    w = make_weights(shapes, 72)
+    with torch.no_grad():
+        for k, prm in named.items():
+            prm.copy_(w[k])
+    m.train()
+    inputs, labels = prompt_ftn_inputs(73)
+    none, score_map = m(inputs)                    # the reference's own forward
+    assert none is None and tuple(score_map.shape) == (1, 6, 512, 512)
+    loss = nn.CrossEntropyLoss()(score_map, labels)
+    loss.backward()
+    grads = {k: (prm.grad.detach().clone() if prm.grad is not None else None) for k, prm in named.items()}
+    keep = ["visual_encoder.encoder.embeddings.patch_embeddings.projection.weight",
+            "visual_encoder.encoder.encoder.layers.3.blocks.0.attention.self.query.weight",
+            "prompt_decoder.layers.0.multihead_attn.k_proj_weight", "prompt_decoder.layers.1.linear2.weight",
+            "decoder.linear2_stage_1.weight", "decoder.linear2_stage_4.weight",
+            "decoder.attention_stage_4.2.attention_block.sr.weight", "decoder.attention_stage_2.0.attention_block.linear1.weight"]
+    keep = [k for k in keep if grads.get(k) is not None]
+    assert len(keep) >= 6, [k for k in named if "stage_4.2" in k][:8]
+    fx = dict(shapes={k: torch.tensor(v) for k, v in shapes.items()}, wseed=torch.tensor(72), iseed=torch.tensor(73),
+              score_s8=score_map.detach()[:, :, ::8, ::8].clone(), loss=loss.detach().clone(),
+              no_grad=[k for k, v in grads.items() if v is None],
+              grad_stats={k: torch.stack([v.sum(), v.abs().sum()]) for k, v in grads.items() if v is not None},
+              grad_full={k: (grads[k] if grads[k].numel() <= 65536 else grads[k].flatten()[::37].clone()) for k in keep})   # big ones: every 37th element
+    torch.save(fx, OUT / "prompt_ftn.pt")
+    print("prompt_ftn: loss", float(loss), "params", len(shapes), "frozen", len(fx["no_grad"]), "full grads", keep)
+
+
+def make_dense_clip(R):
+    """DenseClip.forward (model/model.py:122-171) through the reference's own classes at tiny dims: ImageEncoderCLIPFull
+    (hidden 256, 2 layers, 64 x 64 / patch 16 -> 17 tokens), frozen TextEncoderCLIPPooler (width 64), TextToPatch(out 128),
+    PromptDecoder(PromptLayer(128, 128, 2, dropout 0, batch_first=True), 2) — the reference's ``PromptLayer(d_model=512, nhead=8)``
+    lacks the required d_kv and batch_first and cannot be constructed; d_kv = d_model and batch_first=True is the only reading
+    its forward admits — and DecoderBlock(DecoderLayer(256, 128, 2, batch_first=True, norm_first=True), 2) (head_dim 64 / 128:
+    what the HIP attention kernels take).  Only
+    DenseClip.__init__ is bypassed.  Kept: score_map, out, and gradients of loss = <score_map, ds> + <out, do>."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    from golden_util import dense_clip_inputs, make_weights
+    torch.manual_seed(81)
+    vcfg = R["CLIPVisionConfig"](hidden_size=256, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
+                                 image_size=64, patch_size=16)
+    tcfg = R["CLIPTextConfig"](vocab_size=512, hidden_size=64, intermediate_size=128, num_hidden_layers=1,
+                               num_attention_heads=1, max_position_embeddings=16, eos_token_id=511, bos_token_id=510,
+                               pad_token_id=511)
+    m = _bare(R["rmodel"].DenseClip)
+    m.patch_size, m.in_size, m.out_size = 16, 64, 16
+    m.vision_encoder = _bare(R["renc"].ImageEncoderCLIPFull)
+    m.vision_encoder.in_size, m.vision_encoder.patch_size = 64, 16
+    m.vision_encoder.enc = R["CLIPVisionModel"](vcfg)
+    m.text_encoder = _bare(R["renc"].TextEncoderCLIPPooler)
+    m.text_encoder.patch_size = 16
+    m.text_encoder.enc = R["CLIPTextModel"](tcfg)
+    for prm in m.text_encoder.parameters():
+        prm.requires_grad = False
+    m.text_patch = R["rtp"].TextToPatch(out=128, img_in=256, text_in=64)
+    m.prompt_decoder = R["rdec"].PromptDecoder(R["rdec"].PromptLayer(d_model=128, d_kv=128, nhead=2, dim_feedforward=128, dropout=0.0,
+                                                                    batch_first=True), num_layers=2)
+    m.vision_decoder = R["rdec"].DecoderBlock(decoder_layer=R["rdec"].DecoderLayer(d_model=256, d_kv=128, nhead=2, dim_feedforward=128,
+                                                                                  batch_first=True, norm_first=True), num_layers=2)
+    named = dict(m.named_parameters())
+    shapes = {k: list(v.shape) for k, v in named.items()}
+    w = make_weights(shapes, 82)
+    with torch.no_grad():
+        for k, prm in named.items():
+            prm.copy_(w[k])
+    m.train()
+    inputs, ds, do = dense_clip_inputs(83)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):          # (the reference's forward prints a shape line, model.py:167)
+        none, score_map, out = m(inputs)
+    assert none is None and tuple(score_map.shape) == (2, 5, 4, 4) and tuple(out.shape) == (2, 17, 256)
+    ((score_map * ds).sum() + (out * do).sum()).backward()
+    grads = {k: (prm.grad.detach().clone() if prm.grad is not None else None) for k, prm in named.items()}
+    keep = ["vision_encoder.enc.embeddings.class_embedding", "vision_encoder.enc.encoder.layers.1.mlp.fc2.weight",
+            "text_patch.visual.weight", "text_patch.textual.weight", "prompt_decoder.layers.1.multihead_attn.in_proj_weight",
+            "vision_decoder.layers.0.multihead_attn.k_proj_weight", "vision_decoder.layers.1.linear1.weight"]
+    fx = dict(shapes={k: torch.tensor(v) for k, v in shapes.items()}, wseed=torch.tensor(82), iseed=torch.tensor(83),
+              score_map=score_map.detach().clone(), out=out.detach().clone(), no_grad=[k for k, v in grads.items() if v is None],
+              grad_stats={k: torch.stack([v.sum(), v.abs().sum()]) for k, v in grads.items() if v is not None},
+              grad_full={k: grads[k] for k in keep})
+    torch.save(fx, OUT / "dense_clip_tiny.pt")
+    print("dense_clip: score_map", tuple(score_map.shape), "out", tuple(out.shape), "frozen", len(fx["no_grad"]))
+
+
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
     R = _ref_imports()
@@ -582,6 +700,10 @@ def main():
         make_dropout(R)
         make_swin_droppath(R)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "compose":
+        make_prompt_ftn(R)
+        make_dense_clip(R)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "prompt":
         make_prompt(R)
         make_clip_full(R)
@@ -597,6 +719,8 @@ def main():
     make_clip_full(R)
     make_dropout(R)
     make_swin_droppath(R)
+    make_prompt_ftn(R)
+    make_dense_clip(R)
     # the reference's only data fixture on this path — copied as-is
     protos = torch.load(REF / "model" / "ade20k_prototypes.pt", weights_only=True)
     torch.save(protos.clone(), OUT / "ade20k_prototypes.pt")
