@@ -13,6 +13,8 @@
 #include "common.h"
 #include "lc2is_hip.h"
 #include <cstdlib>
+#include <mutex>
+#include <vector>
 #include <type_traits>
 
 namespace {
@@ -760,6 +762,17 @@ inline void tg_plan(const lc2is_tn_problem* pr, int n, TgPlan& pl) {
 }
 }  // namespace
 
+static std::mutex g_captured_mu;
+static std::vector<void*> g_captured_tables;   // pinned descriptor-table images of captured grouped launches
+
+extern "C" int lc2is_release_captured_tables(void) {
+  std::lock_guard<std::mutex> lock(g_captured_mu);
+  const int n = (int)g_captured_tables.size();
+  for (void* p : g_captured_tables) (void)hipHostFree(p);
+  g_captured_tables.clear();
+  return n;
+}
+
 extern "C" size_t lc2is_gemm_tn_grouped_workspace_bytes(const lc2is_tn_problem* problems, int n) {
   if (tg_valid(problems, n) != LC2IS_OK) return 0;
   TgPlan pl;
@@ -780,7 +793,7 @@ extern "C" int lc2is_gemm_tn_grouped(const lc2is_tn_problem* problems, int n, vo
   // Host image of the table: a ring of PINNED slots, each guarded by an event recorded behind its upload, so a slot is
   // never rewritten while an asynchronous H2D copy may still be reading it (whatever the runtime does with pageable memory).
   // Under stream capture the upload becomes a memcpy node that re-reads its host source at EVERY replay, so a captured
-  // call gets a pinned image of its own that is never reused (a few KB per captured launch, kept for the process lifetime).
+  // call gets a pinned image of its own that is never reused; it lives as long as its graph (lc2is_release_captured_tables).
   struct TblSlot { TnGroupTbl* host; hipEvent_t done; bool in_flight; };
   static thread_local TblSlot ring[4] = {};
   static thread_local unsigned ring_pos = 0;
@@ -796,6 +809,10 @@ extern "C" int lc2is_gemm_tn_grouped(const lc2is_tn_problem* problems, int n, vo
       if (hipThreadExchangeStreamCaptureMode(&mode) != hipSuccess) return LC2IS_ERR_LAUNCH;
       const hipError_t e = hipHostMalloc((void**)&captured_tbl, sizeof(TnGroupTbl), hipHostMallocDefault);
       if (hipThreadExchangeStreamCaptureMode(&mode) != hipSuccess || e != hipSuccess) return LC2IS_ERR_LAUNCH;
+      {   // owned by the graph being captured: remembered so that lc2is_release_captured_tables() can free it with the graph
+        std::lock_guard<std::mutex> lock(g_captured_mu);
+        g_captured_tables.push_back(captured_tbl);
+      }
     } else {
       slot = &ring[ring_pos++ & 3];
       if (!slot->host) {

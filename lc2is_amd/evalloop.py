@@ -40,19 +40,27 @@ class Evaluator:
     """``Engine``'s evaluation half with the same constructor argument names (engine.py:15-21)."""
 
     def __init__(self, model: nn.Module, eval_loader: Iterable, criterion: nn.Module, aux_criterion: nn.Module | None = None,
-                 compute_metrics: Callable | None = segmentation_metrics, device="cuda") -> None:
+                 compute_metrics: Callable | None = segmentation_metrics, device="cuda", keep_outputs: bool = False) -> None:
         self.model = model
         self.eval_loader = eval_loader
         self.criterion = criterion
         self.aux_criterion = aux_criterion
         self.compute_metrics = compute_metrics
         self.device = torch.device(device)
+        # With the default metric (a mean of per-image values) nothing but those values is kept between batches: the reference
+        # concatenates every batch's logits (on the host, engine.py:162-163), which on the device would be ~20 GB (+ as much again
+        # for the cat) over the 2000-image ADE20K validation split at 128 x 128.  ``keep_outputs=True`` (or a custom
+        # ``compute_metrics``, whose contract is ``compute_metrics(outputs=..., labels=...)``) restores the concatenation.
+        self.keep_outputs = keep_outputs or (compute_metrics is not None and compute_metrics is not segmentation_metrics)
         self.model.to(self.device)
 
     def evaluate(self) -> dict:
         eval_metrics, eval_outputs = self.eval_loop()
         if self.compute_metrics is not None:
-            m = self.compute_metrics(**eval_outputs)
+            if "per_image_mIOU" in eval_outputs:
+                m = dict(mIOU_label=float(eval_outputs["per_image_mIOU"].mean().item()))
+            else:
+                m = self.compute_metrics(**eval_outputs)
             eval_metrics = {**eval_metrics, **{"eval_" + k: v for k, v in m.items()}}
         return eval_metrics
 
@@ -71,8 +79,14 @@ class Evaluator:
                     step["eval_aux_loss"] = self.aux_criterion(outputs_dict["low_score_map"], labels) * 0.4
             for k, v in step.items():
                 losses.setdefault(k, []).append(v.detach().float().reshape(()))
-            outs.append(outputs_dict["outputs"])
-            labs.append(labels)
+            if self.keep_outputs or self.compute_metrics is None:
+                outs.append(outputs_dict["outputs"])
+                labs.append(labels)
+            else:
+                outs.append(_metrics.per_image_mIOU(outputs_dict["outputs"], labels))
         eval_metrics = {k: float(torch.stack(v).mean().item()) for k, v in losses.items()}
-        eval_outputs = dict(outputs=torch.cat(outs), labels=torch.cat(labs))
+        if self.keep_outputs or self.compute_metrics is None:
+            eval_outputs = dict(outputs=torch.cat(outs), labels=torch.cat(labs))
+        else:
+            eval_outputs = dict(per_image_mIOU=torch.cat(outs))
         return eval_metrics, eval_outputs

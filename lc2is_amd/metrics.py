@@ -11,7 +11,9 @@ import torch
 from . import ops
 
 
-def compute_mIOU(outputs: torch.Tensor, labels: torch.Tensor, n_cls: int = 151, ignore_index: int | None = 0) -> dict:
+def per_image_mIOU(outputs: torch.Tensor, labels: torch.Tensor, n_cls: int = 151, ignore_index: int | None = 0) -> torch.Tensor:
+    """The per-image values whose mean ``compute_mIOU`` returns (float64 [N] on the device; NaN for an image whose label holds
+    nothing but ``ignore_index``).  ``Evaluator`` accumulates these batch by batch instead of keeping every batch's logits."""
     if not outputs.is_cuda:
         raise RuntimeError("lc2is_amd.metrics: outputs must be on the GPU (no CPU path)")
     N, K, h, w = outputs.shape
@@ -28,5 +30,8 @@ def compute_mIOU(outputs: torch.Tensor, labels: torch.Tensor, n_cls: int = 151, 
         present[:, ignore_index] = False
     # an image whose label holds nothing but ignore_index: the reference takes the mean of an EMPTY selection (metrics.py:94-97),
     # which is NaN, and the mean over images (:101) inherits it — 0 / 0 here reproduces that instead of scoring the image 0
-    per_img = (iou * present).sum(1) / present.sum(1).to(torch.float64)
-    return dict(mIOU_label=float(per_img.mean().item()))
+    return (iou * present).sum(1) / present.sum(1).to(torch.float64)
+
+
+def compute_mIOU(outputs: torch.Tensor, labels: torch.Tensor, n_cls: int = 151, ignore_index: int | None = 0) -> dict:
+    return dict(mIOU_label=float(per_image_mIOU(outputs, labels, n_cls, ignore_index).mean().item()))

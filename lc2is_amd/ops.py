@@ -70,6 +70,7 @@ _ARGTYPES = {
     "lc2is_npair_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "lc2is_gemm_tn_grouped_workspace_bytes": [_P, _I],
     "lc2is_gemm_tn_grouped": [_P, _I, _P, _Z, _P],
+    "lc2is_release_captured_tables": [],
     "lc2is_rows_gather": [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _P],
     "lc2is_resample_u8": [_P, _I, _I, _I, _P, _I, _I, _P, _P, _I, _P],
     "lc2is_gather2d_u8": [_P, _I, _I, _I, _P, _I, _I, _P, _P, _P],
@@ -254,6 +255,14 @@ def gemm_tn_grouped(problems):
     ws = workspace(nbytes, problems[0][0].device, "gemm_tn_grouped")
     rc = _fn("lc2is_gemm_tn_grouped")(arr, len(problems), _ptr(ws), ws.numel(), _stream())
     _lib.check(rc, f"gemm_tn_grouped n={len(problems)}")
+
+
+def release_captured_tables() -> int:
+    """Free the pinned descriptor-table images that captured grouped weight-gradient launches left behind (call after the
+    graphs that captured them are destroyed).  Returns the number freed."""
+    f = _fn("lc2is_release_captured_tables")
+    f.restype = C.c_int
+    return int(f())
 
 
 def colsum(dy: torch.Tensor, db: torch.Tensor | None = None, accumulate: bool = False):

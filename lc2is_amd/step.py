@@ -120,5 +120,12 @@ class TrainStep:
             self.t += 1
             return static_loss
 
-        replay.static_inputs, replay.static_labels, replay.graph = static_in, static_lb, graph
+        def release() -> None:
+            """Destroy the captured graph and the pinned descriptor tables its grouped launches own (the only captured step
+            alive: the tables are process-wide).  The replay function must not be called afterwards."""
+            torch.cuda.synchronize()
+            graph.reset()
+            ops.release_captured_tables()
+
+        replay.static_inputs, replay.static_labels, replay.graph, replay.release = static_in, static_lb, graph, release
         return replay

@@ -40,13 +40,34 @@ def _worker(rank, world, port, q, backend="gloo"):
     from lc2is_amd.step import TrainStep
     m, fx = _build(dev)
     red = GradReducer(bucket_elems=100_000)     # small buckets: the per-layer early reductions of the towers are exercised
+    calls = []                                   # the (lo, hi) sequence of collectives this rank issues, in issue order
+    orig_all_reduce = dist.all_reduce
+
+    def recording_all_reduce(t, *a, **kw):
+        if t.data_ptr() >= red._flat.data_ptr() and t.numel() and t.dtype == red._flat.dtype:
+            lo = (t.data_ptr() - red._flat.data_ptr()) // 4
+            calls.append((int(lo), int(lo + t.numel())))
+        return orig_all_reduce(t, *a, **kw)
+
+    dist.all_reduce = recording_all_reduce
     ts = TrainStep(m, optimizer="sgd", lr=0.05, reducer=red)
     red.broadcast_params(ts.arena.flat, src=0)
     inputs = {k: fx[k][rank:rank + 1].to(dev) for k in ("pixel_values", "input_ids", "attention_mask")}
     labels = fx["labels"][rank:rank + 1].to(dev)
     loss = ts.step(inputs, labels)
     torch.cuda.synchronize()
-    torch.save(dict(rank=rank, loss=float(loss.item()), flat=ts.arena.flat.cpu(), grad=(ts.arena.grad / world).cpu()),
+    flat1, grad1 = ts.arena.flat.cpu().clone(), (ts.arena.grad / world).cpu().clone()
+    first = list(calls)
+    # a second step on DIFFERENT content per rank (rank 1: other pixels, a longer prompt mask): the sequence must not depend on data
+    calls.clear()
+    g = torch.Generator().manual_seed(100 + rank)
+    inputs2 = dict(inputs, pixel_values=torch.randn(inputs["pixel_values"].shape, generator=g).to(dev) * (1 + 3 * rank))
+    if rank == 1:
+        inputs2["attention_mask"] = torch.ones_like(inputs["attention_mask"])
+    ts.step(inputs2, labels)
+    torch.cuda.synchronize()
+    torch.save(dict(rank=rank, loss=float(loss.item()), flat=flat1, grad=grad1, flat2=ts.arena.flat.cpu(),
+                    calls1=torch.tensor(first), calls2=torch.tensor(calls)),
                os.path.join(q, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -82,6 +103,12 @@ def test_two_rank_step_matches_global_batch(dev, tmp_path, backend):
     l0, p0, g0, l1, p1, g1 = r0["loss"], r0["flat"], r0["grad"], r1["loss"], r1["flat"], r1["grad"]
     assert torch.equal(p0, p1), "replicas diverged after one DP step"
     assert torch.equal(g0, g1)
+    assert torch.equal(r0["flat2"], r1["flat2"]), "replicas diverged after the second step"
+    # the property RCCL deadlocks on when violated: every rank issues the SAME sequence of collectives (same slices, same order),
+    # whatever its batch holds — the bucket flushes are driven by the backward's program order, not by data or stream timing
+    assert r0["calls1"].numel() > 0 and r0["calls1"].shape[0] >= 4, r0["calls1"].shape
+    assert torch.equal(r0["calls1"], r1["calls1"]) and torch.equal(r0["calls2"], r1["calls2"])
+    assert torch.equal(r0["calls1"], r0["calls2"])
     # single process on the global batch of 2
     from lc2is_amd.step import TrainStep
     m, fx = _build(dev)
