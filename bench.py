@@ -250,6 +250,16 @@ def main():
     model = N.BaseModelWithText(patch_size=args.patch, in_size=in_size, out_size=out_size).to(dev).train()
     if os.environ.get("LC2IS_SERIAL_TEXT"):   # A/B switch: keep the text tower on the main stream
         model.overlap_text = False
+    diag_cached_text = bool(os.environ.get("LC2IS_BENCH_CACHED_TEXT"))
+    if diag_cached_text:   # DIAGNOSTIC (not a benchmark result: work is skipped): the text tower's output is computed once and reused, which
+        _te, _cache = model.text_encoder, {}   # bounds from above what the tower costs the step while it runs beside the vision tower
+
+        def _cached_text(input_ids, attention_mask=None):
+            if "t" not in _cache:
+                with torch.no_grad():
+                    _cache["t"] = type(_te).forward(_te, input_ids, attention_mask).detach()
+            return _cache["t"]
+        _te.forward = _cached_text
     if world > 1:
         reducer = GradReducer()
     ts = TrainStep(model, optimizer=args.optimizer, lr=1e-5, reducer=reducer)  # all_args.sh:15 LR
@@ -312,6 +322,7 @@ def main():
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "params_M": round(ts.arena.numel / 1e6, 2)},
             "final_loss": loss_val,
+            **({"diagnostic": "LC2IS_BENCH_CACHED_TEXT: the text tower is skipped — NOT a benchmark result"} if diag_cached_text else {}),
             "roofline": {"bound": "mfma", "kernel": "256x256 LDS-DMA NT GEMM: gemm_nt_dma_kernel<256,256,2,4,0,*> + gemm_nt_persist2_kernel<*> (every launch of each 4th timed step)",
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": ref.get("dominant_kernel_hbm_bytes_per_launch"),
