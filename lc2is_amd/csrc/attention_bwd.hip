@@ -15,7 +15,6 @@
 // (ds_read_b64_tr_b16, A operand of the transposed products) from ONE LDS image, made conflict-free for
 // both by an XOR swizzle of the 16-byte chunk index (128-byte rows for D=64, 256-byte rows otherwise).
 #include "attn_common.h"
-#include "attn_tail.h"
 #include "lc2is_hip.h"
 #include <cstdlib>
 
@@ -37,8 +36,6 @@ struct AttnBwdArgs {
   float scale, scale_log2;
   int causal;
   DropCfg drop;        // attention-probability dropout of the forward (DROP instantiations only)
-  int nqb, qtail;      // dQ kernel: 128-query blocks per (batch, head) on the tiled path; qtail: the last row goes to a tail block
-  int nkb, ktail;      // dK/dV kernel: the same for the 128-key blocks (attn_tail.h)
 };
 
 constexpr float LOG2E = 1.44269504088896341f;
@@ -109,14 +106,8 @@ __global__ __launch_bounds__(256, (D == 64) ? LC2IS_DQ2_WAVES : (D <= 96 ? 2 : 1
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hh = lane >> 5, l31 = lane & 31;
-  const int nqb = p.nqb, nmain = nqb * p.H * p.B, ntail = p.qtail ? p.H * p.B : 0;   // 1-D XCD-aware grid (see attention_fwd.hip)
-  if ((int)blockIdx.x < ntail) {   // tail blocks (first in the grid): the last query row of S = 128 n + 1
-    if constexpr (D == 64 && !DROP)
-      attn_bwd_tail_dq_row(p.Q, p.ldq, p.K, p.ldk, p.V, p.ldv, p.O, p.ldo, p.dO, p.lddo, p.dQ, p.lddq, p.lse2, p.delta, p.H, p.Sq,
-                           p.Sk, p.scale, p.scale_log2, blockIdx.x / p.H, blockIdx.x % p.H, smem);
-    return;
-  }
-  const int tile = xcd_remap(blockIdx.x - ntail, nmain);
+  const int nqb = (p.Sq + 127) / 128;   // 1-D XCD-aware grid (see attention_fwd.hip)
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int bx = tile % nqb, head = (tile / nqb) % p.H, b = tile / (nqb * p.H);
   const int q0 = bx * 128 + wid * 32;
   const int qrow = q0 + l31;
@@ -393,14 +384,8 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(A
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int hh = lane >> 5, l31 = lane & 31;
-  const int nkb = p.nkb, nmain = nkb * p.H * p.B, ntail = p.ktail ? p.H * p.B : 0;   // 1-D XCD-aware grid: the key blocks of one (batch, head) sweep the same Q / dO
-  if ((int)blockIdx.x < ntail) {   // tail blocks (first in the grid): the last key column of S = 128 n + 1
-    if constexpr (D == 64 && !DROP)
-      attn_bwd_tail_dkdv_col(p.Q, p.ldq, p.K, p.ldk, p.V, p.ldv, p.dO, p.lddo, p.dK, p.lddk, p.dV, p.lddv, p.lse2, p.delta, p.H,
-                             p.Sq, p.Sk, p.scale, p.scale_log2, blockIdx.x / p.H, blockIdx.x % p.H, smem);
-    return;
-  }
-  const int tile = xcd_remap(blockIdx.x - ntail, nmain);
+  const int nkb = (p.Sk + 127) / 128;   // 1-D XCD-aware grid: the key blocks of one (batch, head) sweep the same Q / dO
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int bx = tile % nkb, head = (tile / nkb) % p.H, b = tile / (nkb * p.H);
   const int kcol = bx * 128 + wid * 32 + l31;
   const bool kok = kcol < p.Sk;
@@ -622,10 +607,10 @@ int launch_attn_bwd(const AttnBwdArgs& a, hipStream_t stream) {
       return LC2IS_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL(k1b, dim3((a.nqb + a.qtail) * a.H * a.B), dim3(256), LDS_DQ2, stream, a);
+  hipLaunchKernelGGL(k1b, dim3(((a.Sq + 127) / 128) * a.H * a.B), dim3(256), LDS_DQ2, stream, a);
   int rc = lc2is_check_launch();
   if (rc) return rc;
-  hipLaunchKernelGGL(k2, dim3((a.nkb + a.ktail) * a.H * a.B), dim3(256), LDS_KV, stream, a);
+  hipLaunchKernelGGL(k2, dim3(((a.Sk + 127) / 128) * a.H * a.B), dim3(256), LDS_KV, stream, a);
   return lc2is_check_launch();
 }
 
@@ -653,11 +638,7 @@ static int attention_bwd_impl(const void* Q, int ldq, const void* K, int ldk, co
     return LC2IS_ERR_UNSUPPORTED;
   AttnBwdArgs a{(const bf16_t*)Q, ldq, (const bf16_t*)K, ldk, (const bf16_t*)V, ldv, (const bf16_t*)O, ldo,
                 (const bf16_t*)dO, lddo, (bf16_t*)dQ, lddq, (bf16_t*)dK, lddk, (bf16_t*)dV, lddv, lse2, delta,
-                kbias, B, H, Sq, Sk, scale, scale * LOG2E, causal, make_drop_cfg(p_drop, seed), (Sq + 127) / 128, 0, (Sk + 127) / 128, 0};
-  if (D == TAIL_D && !causal && !kbias && !a.drop.thr && Sq <= 256 * TAIL_MAX_PER_THREAD && Sk <= 256 * TAIL_MAX_PER_THREAD) {
-    if (Sq > 128 && Sq % 128 == 1) { a.nqb = Sq / 128; a.qtail = 1; }   // the last query row / key column of S = 128 n + 1 (ViT: 1025 tokens)
-    if (Sk > 128 && Sk % 128 == 1) { a.nkb = Sk / 128; a.ktail = 1; }   // leave the tiled paths (attn_tail.h)
-  }
+                kbias, B, H, Sq, Sk, scale, scale * LOG2E, causal, make_drop_cfg(p_drop, seed)};
   if (a.drop.thr) {
     if ((double)B * H * Sq >= 4294967296.0) return LC2IS_ERR_UNSUPPORTED;
     switch (D) {

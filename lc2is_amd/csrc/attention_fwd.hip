@@ -17,7 +17,6 @@
 // registers) into a ring of swizzled images (attn_common.h) that both kinds of read take without bank conflicts.
 // Masks (key tail, key padding, causal) are applied per score, only in tiles that need one.
 #include "attn_common.h"
-#include "attn_tail.h"
 #include "lc2is_hip.h"
 #include <cstdlib>
 
@@ -34,8 +33,6 @@ struct AttnFwdArgs {
   float scale_log2;     // softmax scale * log2(e)
   int causal;
   DropCfg drop;         // attention-probability dropout (DROP instantiations only)
-  int nqb;              // 128-query blocks per (batch, head) on the tiled path; with `tail` the last row (Sq = 128 nqb + 1) goes
-  int tail;             // to one vector-arithmetic block per (batch, head) at the end of the grid (attn_tail.h)
 };
 
 // Structure.  Measured on MI355X at S = 1025, D = 64 (rocprofv3 SQ counters — tools/pmc_attn.sh —, s_memtime phase stamps of a diagnostic build
@@ -77,16 +74,8 @@ __global__ __launch_bounds__(256, (D == 64) ? 3 : 2) void attn_fwd_kernel(AttnFw
   const int hh = lane >> 5, l31 = lane & 31;
   // 1-D grid, XCD-aware: the query blocks of one (batch, head) — which stream the same K / V — are neighbours in the tile
   // order, and xcd_remap gives every XCD (its own L2) one contiguous chunk of that order
-  // (the tail blocks come FIRST in the grid: short, latency-bound blocks that finish under the first round of tiled blocks; at the
-  //  end of the grid they ran alone after the last round — measured slower than the padded ninth block they replace)
-  const int nqb = p.nqb, nmain = nqb * p.H * p.B, ntail = p.tail ? p.H * p.B : 0;
-  if ((int)blockIdx.x < ntail) {   // block-uniform; no barrier has been executed
-    if constexpr (D == 64 && !DROP)
-      attn_fwd_tail_row(p.Q, p.ldq, p.K, p.ldk, p.V, p.ldv, p.O, p.ldo, p.lse2, p.H, p.Sq, p.Sk, p.scale_log2, blockIdx.x / p.H,
-                        blockIdx.x % p.H, smem);
-    return;
-  }
-  const int tile = xcd_remap(blockIdx.x - ntail, nmain);
+  const int nqb = (p.Sq + QB - 1) / QB;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int bx = tile % nqb, head = (tile / nqb) % p.H, b = tile / (nqb * p.H);
   const int q0 = bx * QB + wid * 32;                  // first query of this wave
   const int qrow = q0 + l31;
@@ -370,7 +359,7 @@ int launch_attn_fwd(const AttnFwdArgs& a, hipStream_t stream) {
       return LC2IS_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((a.nqb + a.tail) * a.H * a.B), dim3(256), LDS, stream, a);
+  hipLaunchKernelGGL(kern, dim3(((a.Sq + 127) / 128) * a.H * a.B), dim3(256), LDS, stream, a);
   return lc2is_check_launch();
 }
 
@@ -391,12 +380,7 @@ static int attention_fwd_impl(const void* Q, int ldq, const void* K, int ldk, co
       (double)B * (Sk + 64) * ldv * 2.0 >= 2147483648.0)
     return LC2IS_ERR_UNSUPPORTED;
   AttnFwdArgs a{(const bf16_t*)Q, ldq, (const bf16_t*)K, ldk, (const bf16_t*)V, ldv, (bf16_t*)O, ldo, lse2,
-                kbias, B, H, Sq, Sk, scale * 1.44269504088896341f, causal, make_drop_cfg(p_drop, seed), (Sq + 127) / 128, 0};
-  // the ragged last row of S = 128 n + 1 (ViT: 1025 tokens) leaves the tiled path (attn_tail.h)
-  if (D == TAIL_D && !causal && !kbias && !a.drop.thr && Sq > 128 && Sq % 128 == 1 && Sk <= 256 * TAIL_MAX_PER_THREAD) {
-    a.nqb = Sq / 128;
-    a.tail = 1;
-  }
+                kbias, B, H, Sq, Sk, scale * 1.44269504088896341f, causal, make_drop_cfg(p_drop, seed)};
   if (a.drop.thr) {
     if ((double)B * H * Sq >= 4294967296.0) return LC2IS_ERR_UNSUPPORTED;   // 32-bit row coordinate of the RNG
     switch (D) {

@@ -41,10 +41,10 @@ CASES = [
     # round 3: config 5 at its real size — spatial-reduction attention of the 64x64 stage (queries 4096, keys 4096 / 4 after the
     # 2x2 stride-2 conv, model/hierarchical.py:214-219), 8 heads x 64
     (1, 8, 4096, 1024, 64, False, False, False),
-    # the ragged last row of S = 128 n + 1 leaves the tiled kernels for the vector-arithmetic tail blocks (attn_tail.h): also taken
-    # by the 1025- and 129-query cases above; here with different query / key counts (both ragged) and many heads
+    # ragged last tiles of at most 32 rows (S = 64 n + 1: the empty second half of the tile is skipped in all three kernels), with
+    # different query / key counts and many heads; and the ViT token count with a key-padding mask
     (2, 5, 257, 385, 64, False, False, False),
-    (1, 2, 1025, 1025, 64, False, True, True),    # the same token count WITH a key-padding mask: stays on the tiled path
+    (1, 2, 1025, 1025, 64, False, True, True),
 ]
 
 
