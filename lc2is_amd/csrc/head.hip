@@ -9,13 +9,15 @@
 // Cp = padded class count) with two small MFMA GEMMs and this kernel interpolates 151 channels instead of
 // 768 — the [B,16384,768] tensor (25 MB/img) is never materialised.
 //
-// Work split: a block owns a 16x16 tile of OUTPUT pixels.  The <=7x7 low-res footprint of the tile
-// (S >= 4) is staged in LDS once; each wave then walks 64 output pixels with the 64 lanes spread over
-// CHANNELS (3 per lane, C <= 192): LDS reads, the softmax reductions and the gradient scatter are all
-// lane-contiguous (conflict-free ds_read / ds_add_f32).  The gradient wrt the low-res scores is accumulated
-// in an LDS mirror of the footprint and flushed with one fp32 atomic add per footprint element — 256-byte
-// contiguous segments, the shape global float atomics run at full rate.  HBM traffic: the low-res scores
-// and labels once, the low-res gradient once.
+// Work split: a block owns a 16x16 tile of OUTPUT pixels; the <=7x7 low-res footprint of the tile (S >= 4) is staged in LDS
+// once, the gradient wrt the low-res scores is accumulated in an LDS mirror of the footprint and flushed with one fp32 atomic
+// add per footprint element — 256-byte contiguous segments, the shape global float atomics run at full rate.  HBM traffic:
+// the low-res scores and labels once, the low-res gradient once.
+//  * S == 4 (the headline bicubic head and config 5's bilinear score map): head_ce_s4_kernel — 4x4-pixel groups as two small
+//    products on the fp32 matrix pipe, softmax in the accumulator layout, waves taking turns to add their gradient tiles to the
+//    LDS mirror (no LDS atomics: they retire about one lane per three cycles per CU and were 90 % of the first S = 4 kernel).
+//  * other S: head_ce_kernel — each wave walks 64 output pixels with the 64 lanes spread over CHANNELS (3 per lane, C <= 192),
+//    wave reductions for the softmax, ds_add_f32 for the gradient scatter.
 #include "common.h"
 #include "lc2is_hip.h"
 
@@ -25,6 +27,7 @@ constexpr int HT = 16;        // output tile edge
 constexpr int FMAX = 8;       // max footprint edge for S >= 4 (16/S + 4 bicubic rows)
 constexpr int HEAD_THREADS = 512;
 constexpr int CMAX = 192;
+constexpr int HEAD_PAD = 4;     // floats added to a footprint cell's LDS stride in the S = 4 kernel
 
 __device__ __forceinline__ float cubic1(float x) { return ((1.25f * x - 2.25f) * x) * x + 1.f; }          // A=-0.75
 __device__ __forceinline__ float cubic2(float x) { return ((-0.75f * x + 3.75f) * x - 6.f) * x + 3.f; }
@@ -208,19 +211,46 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_ce_kernel(HeadArgs p) {
 }
 
 // ---- fast path: S == 4, bicubic (the headline configuration) or bilinear (config-5 score map, AuxiliaryLoss) ----
-// For S = 4 the output pixels Y in [4a+2, 4a+6) share one tap row set {a-1..a+2} and differ only in the
-// fractional weights t in {1/8, 3/8, 5/8, 7/8}.  Tiles are shifted by 2 pixels so they hold exactly 4x4 such
-// groups; a wave loads a group's 4x4 low-res cells into REGISTERS once (48 values per lane, lanes = channels),
-// evaluates its 16 pixels with separable row/column mixes, accumulates the gradient for the 16 cells in
-// registers, and touches LDS only for the final 48 adds per group (16x fewer LDS reads / atomics than the
-// generic kernel).
-// Bilinear uses the same grouping with 2 taps {a, a+1} and weights {1-t, t}; torch's clamp of the source
-// coordinate at 0 equals clamping the tap indices because the two clamped taps then coincide.
-template <int MODE>
-__global__ __launch_bounds__(HEAD_THREADS) void head_ce_s4_kernel(HeadArgs p) {
+// For S = 4 the output pixels Y in [4a+2, 4a+6) share one tap row set {a-1..a+2} and differ only in the fractional
+// weights t in {1/8, 3/8, 5/8, 7/8}; tiles are shifted by 2 pixels so they hold exactly 4x4 such GROUPS of 4x4 pixels.
+// A group is two small matrix products on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32: an exact k-ordered fp32 fma chain
+// at twice the plain-VALU rate, beside the VALU instead of on it):
+//   logits[16 pixels][C]  = Wm[16 pixels][NT*NT cells] x lo[cells][C]            (forward,  A = weights, B = LDS footprint)
+//   dlo   [cells][C]     += Wm^T[cells][16 pixels]     x dlogits[16 pixels][C]   (backward, B = the forward's accumulators)
+// Wm[pixel (py,px)][cell (i,j)] = w(py,i) * w(px,j).  The accumulator of a 16-channel tile holds, per lane, channel
+// 16t + (lane & 15) of the four pixels (py = lane >> 4, px = 0..3): the softmax over channels is an in-lane loop over the
+// tiles plus four DPP steps inside a 16-lane row, for four pixels at once, and the same registers (now dlogits) are the B
+// operand of the backward product once its A operand is ordered to match (k = lane >> 4 <-> pixel (k, jj) in product jj).
+// The label's own terms — logit[label] for the loss, -gscale * Wm for the gradient — are 16 x NT*NT scalars per group and
+// go through LDS reads / LDS adds with one (pixel, cell quad) per lane.
+// Bilinear uses the same grouping with 2 taps {a, a+1} and weights {1-t, t} (one product of k = 4 per tile); torch's clamp
+// of the source coordinate at 0 equals clamping the tap indices because the two clamped taps then coincide.
+template <int MODE> __device__ __forceinline__ float tap_w(int ph, int k) {
+  const float t = 0.125f + 0.25f * (float)ph;
+  if constexpr (MODE == LC2IS_INTERP_BICUBIC)
+    return k == 0 ? cubic2(t + 1.f) : (k == 1 ? cubic1(t) : (k == 2 ? cubic1(1.f - t) : cubic2(2.f - t)));
+  else
+    return k == 0 ? 1.f - t : t;
+}
+
+template <int CTRL> __device__ __forceinline__ float row_dpp(float v) {   // lane permutation inside each row of 16 lanes
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, row_dpp<0xB1>(v)); v = fmaxf(v, row_dpp<0x4E>(v)); v = fmaxf(v, row_dpp<0x141>(v));
+  return fmaxf(v, row_dpp<0x140>(v));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += row_dpp<0xB1>(v); v += row_dpp<0x4E>(v); v += row_dpp<0x141>(v);
+  return v + row_dpp<0x140>(v);
+}
+
+template <int MODE, int TN>
+__global__ __launch_bounds__(HEAD_THREADS, 2) void head_ce_s4_kernel(HeadArgs p) {
   constexpr int NT = (MODE == LC2IS_INTERP_BICUBIC) ? 4 : 2;   // taps per axis
   constexpr int OFF = (MODE == LC2IS_INTERP_BICUBIC) ? 1 : 0;  // first tap = a - OFF
   constexpr int F4 = 4 + NT - 1;                               // footprint edge: 4 groups + NT - 1
+  constexpr int NQ = NT * NT / 4;                              // k = 4 chunks of the forward product
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int tiles_x = (p.W + 2 + HT - 1) / HT, tiles_y = (p.H + 2 + HT - 1) / HT;
@@ -228,141 +258,169 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_ce_s4_kernel(HeadArgs p) {
   const int tyi = (blockIdx.x / tiles_x) % tiles_y, txi = blockIdx.x % tiles_x;
   const int a0 = 4 * tyi - 1, b0 = 4 * txi - 1;  // "floor" lo index of the tile's first group row / column
   const int Cp = p.ld;
+  const int CS = Cp + HEAD_PAD;                  // cell stride in LDS (floats): the 16 cells of a group on different banks
   float* s_lo = (float*)smem;
-  float* s_dlo = s_lo + F4 * F4 * Cp;
+  float* s_dlo = s_lo + F4 * F4 * CS;
+  int* s_lab = (int*)(s_dlo + F4 * F4 * CS);     // [16][16] pixels of the tile: -2 outside the image, -1 not counted, else label
   const int fsize = F4 * F4 * Cp;
   for (int i = tid * 4; i < fsize; i += HEAD_THREADS * 4) {
     const int cell = i / Cp, c = i % Cp;
     int ry = a0 - OFF + cell / F4, rx = b0 - OFF + cell % F4;
     ry = ry < 0 ? 0 : (ry > p.h - 1 ? p.h - 1 : ry);
     rx = rx < 0 ? 0 : (rx > p.w - 1 ? p.w - 1 : rx);
-    *reinterpret_cast<float4*>(s_lo + i) =
+    *reinterpret_cast<float4*>(s_lo + cell * CS + c) =
         *reinterpret_cast<const float4*>(p.lo + (((size_t)b * p.h + ry) * p.w + rx) * p.ld + c);
-    if (p.dlo) *reinterpret_cast<float4*>(s_dlo + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.dlo) *reinterpret_cast<float4*>(s_dlo + cell * CS + c) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  // weights of the four phases (identical for rows and columns)
-  float wt[4][NT];
-#pragma unroll
-  for (int ph = 0; ph < 4; ++ph) {
-    const float t = 0.125f + 0.25f * (float)ph;
-    if constexpr (NT == 4) {
-      wt[ph][0] = cubic2(t + 1.f); wt[ph][1] = cubic1(t); wt[ph][2] = cubic1(1.f - t); wt[ph][3] = cubic2(2.f - t);
-    } else {
-      wt[ph][0] = 1.f - t; wt[ph][1] = t;
+  if (tid < HT * HT) {
+    const int Y = 4 * a0 + 2 + (tid >> 4), X = 4 * b0 + 2 + (tid & 15);
+    int code = -2;
+    if (Y >= 0 && X >= 0 && Y < p.H && X < p.W) {
+      code = -1;
+      if (p.labels) {
+        const int64_t lab64 = p.labels[((size_t)b * p.H + Y) * p.W + X];
+        if (lab64 != (int64_t)p.ignore_index && lab64 >= 0 && lab64 < p.C) code = (int)lab64;
+      }
     }
+    s_lab[tid] = code;
   }
   __syncthreads();
 
-  const bool c_ok[3] = {lane < p.C, lane + 64 < p.C, lane + 128 < p.C};
+  const int m = lane & 15, kq = lane >> 4;
   const float NEG = -__builtin_inff();
-  // labels of this wave's 32 pixels: lane -> (group lane>>4, py (lane>>2)&3, px lane&3)
-  int my_label = -1;
-  {
-    const int gi = 2 * wid + ((lane >> 4) & 1), gy = gi >> 2, gx = gi & 3;
-    const int Y = 4 * (a0 + gy) + 2 + ((lane >> 2) & 3), X = 4 * (b0 + gx) + 2 + (lane & 3);
-    if (lane < 32 && p.labels && Y >= 0 && X >= 0 && Y < p.H && X < p.W) {
-      const int64_t lab64 = p.labels[((size_t)b * p.H + Y) * p.W + X];
-      my_label = (lab64 == (int64_t)p.ignore_index || lab64 < 0 || lab64 >= p.C) ? -1 : (int)lab64;
-    }
+  constexpr float LOG2E = 1.4426950408889634f;
+  // forward A: row = pixel m (py = m >> 2, px = m & 3), k = kq -> cell 4q + kq.  Backward (transposed: rows = channels, columns =
+  // cells) B of product jj: column = cell m, k = kq -> pixel (py = kq, px = jj)
+  float Af[NQ], Bb[4];
+  int cell_off[NQ];   // LDS float offset of the forward cell, relative to the group's first cell
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int c = 4 * q + kq, i = c / NT, j = c % NT;
+    Af[q] = tap_w<MODE>(m >> 2, i) * tap_w<MODE>(m & 3, j);
+    cell_off[q] = (i * F4 + j) * CS;
   }
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) Bb[jj] = (m < NT * NT) ? tap_w<MODE>(kq, m / NT) * tap_w<MODE>(jj, m % NT) : 0.f;
+  const int cellm_off = ((m / NT) * F4 + m % NT) * CS + 4 * kq;   // this lane's cell / channel quad in the transposed gradient tile
   float loss_acc = 0.f, cnt_acc = 0.f;
 
 #pragma unroll 1
   for (int g2 = 0; g2 < 2; ++g2) {
     const int gi = 2 * wid + g2, gy = gi >> 2, gx = gi & 3;
     const int Yb = 4 * (a0 + gy) + 2, Xb = 4 * (b0 + gx) + 2;
-    if (Yb >= p.H || Xb >= p.W || Yb + 3 < 0 || Xb + 3 < 0) continue;  // wave-uniform
-    float v[NT][NT][3], dacc[NT][NT][3];
+    const bool active = !(Yb >= p.H || Xb >= p.W || Yb + 3 < 0 || Xb + 3 < 0);  // wave-uniform
+    const int gbase = (gy * F4 + gx) * CS;
+    f32x4_t acc[TN];   // logits, then exp, then (as d) the transposed gradient tiles
+    bool have_d = false;
+    if (active) {
 #pragma unroll
-    for (int i = 0; i < NT; ++i)
+      for (int t = 0; t < TN; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const float* cp = s_lo + ((gy + i) * F4 + gx + j) * Cp + lane;
-        v[i][j][0] = cp[0]; v[i][j][1] = cp[64]; v[i][j][2] = cp[128];
-        dacc[i][j][0] = 0.f; dacc[i][j][1] = 0.f; dacc[i][j][2] = 0.f;
+      for (int q = 0; q < NQ; ++q) {
+        const float* bp = s_lo + gbase + cell_off[q] + m;
+        float bv[TN];
+#pragma unroll
+        for (int t = 0; t < TN; ++t) bv[t] = bp[16 * t];
+#pragma unroll
+        for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(Af[q], bv[t], acc[t], 0, 0, 0);
       }
+      // this lane's four accumulator pixels: (py = kq, px = 0..3)
+      const i32x4_t lab4 = *reinterpret_cast<const i32x4_t*>(s_lab + (4 * gy + kq) * 16 + 4 * gx);
+      if (p.hi_out) {
+        const size_t plane = (size_t)p.H * p.W;
 #pragma unroll
-    for (int py = 0; py < 4; ++py) {
-      const int Y = Yb + py;
-      float r[NT][3], tq[NT][3];
+        for (int t = 0; t < TN; ++t) {
+          const int ch = 16 * t + m;
+          if (ch < p.C) {
+            float* o = p.hi_out + ((size_t)b * p.C + ch) * plane + (size_t)(Yb + kq) * p.W + Xb;
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          float acc_r = 0.f;
-#pragma unroll
-          for (int i = 0; i < NT; ++i) acc_r += wt[py][i] * v[i][j][k];
-          r[j][k] = acc_r;
-          tq[j][k] = 0.f;
-        }
-      if (Y >= 0 && Y < p.H) {
-#pragma unroll
-        for (int px = 0; px < 4; ++px) {
-          const int X = Xb + px;
-          if (X < 0 || X >= p.W) continue;  // wave-uniform
-          float lg[3];
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            float acc_l = 0.f;
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc_l += wt[px][j] * r[j][k];
-            lg[k] = acc_l;
-          }
-          if (p.hi_out) {
-            const size_t plane = (size_t)p.H * p.W;
-            float* o = p.hi_out + ((size_t)b * p.C) * plane + (size_t)Y * p.W + X;
-            if (c_ok[0]) o[(size_t)lane * plane] = lg[0];
-            if (c_ok[1]) o[(size_t)(lane + 64) * plane] = lg[1];
-            if (c_ok[2]) o[(size_t)(lane + 128) * plane] = lg[2];
-          }
-          if (!p.loss_sum) continue;
-          const int label = __builtin_amdgcn_readlane(my_label, 16 * g2 + 4 * py + px);   // wave-uniform index: v_readlane
-          float m = fmaxf(fmaxf(c_ok[0] ? lg[0] : NEG, c_ok[1] ? lg[1] : NEG), c_ok[2] ? lg[2] : NEG);
-          m = wave_max(m);
-          float e[3];
-          e[0] = c_ok[0] ? __expf(lg[0] - m) : 0.f;
-          e[1] = c_ok[1] ? __expf(lg[1] - m) : 0.f;
-          e[2] = c_ok[2] ? __expf(lg[2] - m) : 0.f;
-          const float ssum = wave_sum(e[0] + e[1] + e[2]);
-          if (label < 0) continue;
-          const int lsel = label >> 6, llane = label & 63;
-          const float vsel = lsel == 0 ? lg[0] : (lsel == 1 ? lg[1] : lg[2]);
-          loss_acc += (m + __logf(ssum)) - __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vsel), llane));
-          cnt_acc += 1.f;
-          if (p.dlo) {
-            const float inv = p.gscale / ssum;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-              const float gk = e[k] * inv - ((lsel == k && lane == llane) ? p.gscale : 0.f);
-#pragma unroll
-              for (int j = 0; j < NT; ++j) tq[j][k] += wt[px][j] * gk;
-            }
+            for (int r = 0; r < 4; ++r)
+              if (lab4[r] != -2) o[r] = acc[t][r];
           }
         }
       }
+      if (p.loss_sum) {
+        // the label's logit: this lane owns pixel m x cells {4q + kq}
+        const int lab_m = s_lab[(4 * gy + (m >> 2)) * 16 + 4 * gx + (m & 3)];
+        if (lab_m >= 0) {
 #pragma unroll
-      for (int i = 0; i < NT; ++i)
+          for (int q = 0; q < NQ; ++q) loss_acc -= Af[q] * s_lo[gbase + cell_off[q] + lab_m];
+        }
+        // softmax over the channels of four pixels at once
+        float mx[4] = {NEG, NEG, NEG, NEG}, sum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int t = 0; t < TN; ++t) {
+          if (16 * t + 16 > p.C) {   // uniform: a tile with channels past C
+            if (16 * t + m >= p.C) acc[t] = f32x4_t{NEG, NEG, NEG, NEG};
+          }
 #pragma unroll
-          for (int k = 0; k < 3; ++k) dacc[i][j][k] += wt[py][i] * tq[j][k];
+          for (int r = 0; r < 4; ++r) mx[r] = fmaxf(mx[r], acc[t][r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx[r] = row16_max(mx[r]);
+#pragma unroll
+        for (int t = 0; t < TN; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = __builtin_amdgcn_exp2f((acc[t][r] - mx[r]) * LOG2E);
+            acc[t][r] = e;
+            sum[r] += e;
+          }
+        float inv[4];
+        int dl[4];   // label - lane's channel offset: the one-hot sits in tile t where dl == 16 t
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          sum[r] = row16_sum(sum[r]);
+          const bool counted = lab4[r] >= 0;
+          inv[r] = counted ? p.gscale / sum[r] : 0.f;
+          dl[r] = counted ? lab4[r] - m : -1;
+          if (counted && m == 0) {
+            loss_acc += mx[r] + __logf(sum[r]);
+            cnt_acc += 1.f;
+          }
+        }
+        if (p.dlo) {
+          have_d = true;
+#pragma unroll
+          for (int t = 0; t < TN; ++t) {
+            f32x4_t gv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gv[r] = acc[t][r] * inv[r] - (dl[r] == 16 * t ? p.gscale : 0.f);
+            f32x4_t d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) d = __builtin_amdgcn_mfma_f32_16x16x4f32(gv[jj], Bb[jj], d, 0, 0, 0);
+            acc[t] = d;   // d[r] = channel 16 t + 4 kq + r of cell m
+          }
+        }
+      }
     }
+    // The 16 groups of a tile overlap in every footprint cell (bicubic), and LDS float atomics retire about one LANE per three
+    // cycles per CU — 2 800 lane-adds per group made them 90 % of this kernel.  The waves take turns instead: plain 16-byte
+    // read-add-write of the transposed tiles (one cell per lane, four consecutive channels, conflict-free under the padded stride).
+    // Bilinear footprints are 2 x 2 cells: the groups a pass runs on waves of equal (wid >> 1) & 1 sit two cells apart in both
+    // directions, so two turns per pass do.
     if (p.dlo) {
+      constexpr int NTURN = (MODE == LC2IS_INTERP_BICUBIC) ? HEAD_THREADS / 64 : 2;
+      const int my_turn = (MODE == LC2IS_INTERP_BICUBIC) ? wid : ((wid >> 1) & 1);
+      for (int turn = 0; turn < NTURN; ++turn) {
+        __syncthreads();
+        if (turn == my_turn && have_d && m < NT * NT) {
+          float* dp = s_dlo + gbase + cellm_off;
 #pragma unroll
-      for (int i = 0; i < NT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          float* cp = s_dlo + ((gy + i) * F4 + gx + j) * Cp + lane;
-          if (c_ok[0]) lds_add(cp, dacc[i][j][0]);
-          if (c_ok[1]) lds_add(cp + 64, dacc[i][j][1]);
-          if (c_ok[2]) lds_add(cp + 128, dacc[i][j][2]);
+          for (int t = 0; t < TN; ++t) {
+            f32x4_t v = *reinterpret_cast<f32x4_t*>(dp + 16 * t);
+            v += acc[t];
+            *reinterpret_cast<f32x4_t*>(dp + 16 * t) = v;
+          }
         }
+      }
     }
   }
 
   // one pair of atomics per BLOCK: thousands of waves adding to the same two floats serialise in one L2 channel
-  // (that, not the arithmetic, was 80 % of this kernel's time)
   __shared__ float s_red[HEAD_THREADS / 64][2];
+  loss_acc = wave_sum(loss_acc);
+  cnt_acc = wave_sum(cnt_acc);
   if (lane == 0) { s_red[wid][0] = loss_acc; s_red[wid][1] = cnt_acc; }
   __syncthreads();
   if (p.loss_sum && tid == 0) {
@@ -381,7 +439,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_ce_s4_kernel(HeadArgs p) {
       int ry = a0 - OFF + cell / F4, rx = b0 - OFF + cell % F4;
       ry = ry < 0 ? 0 : (ry > p.h - 1 ? p.h - 1 : ry);
       rx = rx < 0 ? 0 : (rx > p.w - 1 ? p.w - 1 : rx);
-      const float val = s_dlo[i];
+      const float val = s_dlo[cell * CS + c];
       if (val != 0.f) atomicAdd(p.dlo + (((size_t)b * p.h + ry) * p.w + rx) * p.ld + c, val);
     }
   }
@@ -518,23 +576,32 @@ extern "C" int lc2is_head_upsample_ce(const float* scores_lo, int ld, const int6
     attr_set = true;
   }
   if (S == 4) {
-    static bool attr4 = false;
+    // channel tiles of 16 the kernel runs (tiles past C are masked): the smallest instantiation that covers C inside the row stride
+    const int nt = (C + 15) / 16;
+    const int tn = nt <= 4 ? 4 : (nt <= 8 ? 8 : (nt <= 10 ? 10 : 12));
     const int f4 = (mode == LC2IS_INTERP_BICUBIC) ? 7 : 5;
-    const int lds4 = 2 * f4 * f4 * ld * (int)sizeof(float);
-    if (!attr4) {
-      const int mx4 = 2 * 7 * 7 * CMAX * (int)sizeof(float);
-      if (hipFuncSetAttribute((const void*)head_ce_s4_kernel<LC2IS_INTERP_BICUBIC>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, mx4) != hipSuccess ||
-          hipFuncSetAttribute((const void*)head_ce_s4_kernel<LC2IS_INTERP_BILINEAR>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, mx4) != hipSuccess)
-        return LC2IS_ERR_LAUNCH;
-      attr4 = true;
-    }
+    const int lds4 = 2 * f4 * f4 * (ld + HEAD_PAD) * (int)sizeof(float) + HT * HT * (int)sizeof(int);
     const int t4 = ((H + 2 + HT - 1) / HT) * ((W + 2 + HT - 1) / HT);
-    if (mode == LC2IS_INTERP_BICUBIC)
-      hipLaunchKernelGGL(head_ce_s4_kernel<LC2IS_INTERP_BICUBIC>, dim3(B * t4), dim3(HEAD_THREADS), lds4, stream, a);
-    else
-      hipLaunchKernelGGL(head_ce_s4_kernel<LC2IS_INTERP_BILINEAR>, dim3(B * t4), dim3(HEAD_THREADS), lds4, stream, a);
+#define LC2IS_HEAD_S4(MODE_, TN_)                                                                                            \
+  do {                                                                                                                      \
+    static bool attr = false;                                                                                               \
+    if (!attr) {                                                                                                            \
+      if (hipFuncSetAttribute((const void*)head_ce_s4_kernel<MODE_, TN_>, hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                              2 * 7 * 7 * (CMAX + HEAD_PAD) * (int)sizeof(float) + HT * HT * (int)sizeof(int)) != hipSuccess) \
+        return LC2IS_ERR_LAUNCH;                                                                                            \
+      attr = true;                                                                                                          \
+    }                                                                                                                       \
+    hipLaunchKernelGGL((head_ce_s4_kernel<MODE_, TN_>), dim3(B * t4), dim3(HEAD_THREADS), lds4, stream, a);                 \
+  } while (0)
+#define LC2IS_HEAD_S4_MODE(MODE_)                                                                                           \
+  do {                                                                                                                      \
+    if (tn == 4) LC2IS_HEAD_S4(MODE_, 4); else if (tn == 8) LC2IS_HEAD_S4(MODE_, 8);                                        \
+    else if (tn == 10) LC2IS_HEAD_S4(MODE_, 10); else LC2IS_HEAD_S4(MODE_, 12);                                             \
+  } while (0)
+    if (mode == LC2IS_INTERP_BICUBIC) LC2IS_HEAD_S4_MODE(LC2IS_INTERP_BICUBIC);
+    else LC2IS_HEAD_S4_MODE(LC2IS_INTERP_BILINEAR);
+#undef LC2IS_HEAD_S4_MODE
+#undef LC2IS_HEAD_S4
     return lc2is_check_launch();
   }
   const int tiles = ((H + HT - 1) / HT) * ((W + HT - 1) / HT);
