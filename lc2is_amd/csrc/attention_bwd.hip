@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256, (D == 64) ? LC2IS_DQ2_WAVES : (D <= 96 ? 2 : 1
 template <int D, bool DROP = false>
 __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
   using I = Img<D>;
-  constexpr int NKS = D / 16, NDT = D / 32, CH = I::CH, NCH = I::NCH;
+  constexpr int NKS = D / 16, NDT = D / 32;
   constexpr int STAGE = 2 * I::TILE + 768;  // Q image, dO image, 64 lse2, 64 delta, 64 dropout row hashes
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -395,8 +395,6 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(A
   const int nqt = (p.Sq + 63) / 64;
   const int qt0 = p.causal ? (bx * 128) / 64 : 0;  // earlier queries see none of these keys
 
-  const __amdgpu_buffer_rsrc_t rsQ = make_rsrc(p.Q, (unsigned)p.B * p.Sq * p.ldq * 2u);
-  const __amdgpu_buffer_rsrc_t rsdO = make_rsrc(p.dO, (unsigned)p.B * p.Sq * p.lddo * 2u);
   const __amdgpu_buffer_rsrc_t rsK = make_rsrc(p.K, (unsigned)p.B * p.Sk * p.ldk * 2u);
   const __amdgpu_buffer_rsrc_t rsV = make_rsrc(p.V, (unsigned)p.B * p.Sk * p.ldv * 2u);
 
@@ -412,23 +410,22 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(A
   }
   const float bias = kok ? (p.kbias ? p.kbias[(size_t)b * p.Sk + kcol] * LOG2E : 0.f) : -INF;
 
-  int q_goff[NCH], g_goff[NCH], t_lds[NCH];
+  // Q / dO tiles of 64 queries arrive by LDS-DMA (the K / V scheme of the dQ kernel: 1-KiB pieces, swizzle on the source side, no
+  // staging registers and no ds_write pass); the rows' lse2 / delta (/ dropout row hashes) still travel through one register.
+  using Cfg = AttnCfg<D>;
+  static_assert(Cfg::TILE == I::TILE && Cfg::PITCH == I::PITCH, "one LDS image for both attention backward kernels");
+  const unsigned qbytes = (unsigned)p.B * p.Sq * p.ldq * 2u, gbytes = (unsigned)p.B * p.Sq * p.lddo * 2u;
+  int q_goff[Cfg::PPW], g_goff[Cfg::PPW];
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int c = tid + i * 256, row = c / CH, ch = c % CH;
-    q_goff[i] = ((b * p.Sq + row) * p.ldq + head * D + ch * 8) * 2;
-    g_goff[i] = ((b * p.Sq + row) * p.lddo + head * D + ch * 8) * 2;
-    t_lds[i] = I::off(row, ch);
+  for (int j = 0; j < Cfg::PPW; ++j) {
+    const int row = Cfg::RPP * (wid * Cfg::PPW + j) + lane / Cfg::SLOTS;
+    const int ch = (lane % Cfg::SLOTS) ^ Cfg::swz(row);
+    q_goff[j] = ch < Cfg::CH ? ((b * p.Sq + row) * p.ldq + head * D + ch * 8) * 2 : -1;
+    g_goff[j] = ch < Cfg::CH ? ((b * p.Sq + row) * p.lddo + head * D + ch * 8) * 2 : -1;
   }
-  i32x4_t rq[NCH], rg[NCH];
   float rstat = 0.f;
-  auto gload = [&](int qt) {
-    const int qb = qt * 64 * p.ldq * 2, gb = qt * 64 * p.lddo * 2;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      rq[i] = __builtin_amdgcn_raw_buffer_load_b128(rsQ, q_goff[i] + qb, 0, 0);
-      rg[i] = __builtin_amdgcn_raw_buffer_load_b128(rsdO, g_goff[i] + gb, 0, 0);
-    }
+  auto gload = [&](int qt, char* stage) {
+    attn_dma_tile<D>(p.Q, qbytes, p.dO, gbytes, stage, wid, q_goff, g_goff, qt * 64 * p.ldq * 2, qt * 64 * p.lddo * 2);
     if (tid < 128) {  // threads 0..63: lse2, 64..127: delta
       const int q = qt * 64 + (tid & 63);
       const size_t si = ((size_t)b * p.H + head) * p.Sq + q;
@@ -443,13 +440,9 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(A
       rstat = __builtin_bit_cast(float, drop_row_hash(p.drop, (unsigned)((b * p.H + head) * p.Sq + q)));
     }
   };
-  auto lstore = [&](char* stage) {
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      *(i32x4_t*)(stage + t_lds[i]) = rq[i];
-      *(i32x4_t*)(stage + I::TILE + t_lds[i]) = rg[i];
-    }
+  auto lstore = [&](char* stage) {   // the row statistics; then every DMA piece this wave requested has landed
     if (tid < (DROP ? 192 : 128)) *(float*)(stage + 2 * I::TILE + tid * 4) = rstat;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
 
   const int q4 = (lane >> 2) & 3, p4 = lane & 3, cg = (lane >> 4) & 1;
@@ -470,7 +463,7 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(A
     for (int r = 0; r < 16; ++r) { dkt[d][r] = 0.f; dvt[d][r] = 0.f; }
 
   if (qt0 < nqt) {
-    gload(qt0);
+    gload(qt0, smem);
     lstore(smem);
   }
   __syncthreads();
@@ -484,7 +477,7 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(A
     const char* cur = smem + (it & 1) * STAGE;
     char* nxt = smem + ((it + 1) & 1) * STAGE;
     const bool more = (qt + 1) < nqt;
-    if (more) gload(qt + 1);
+    if (more) gload(qt + 1, nxt);
     const float* lsev = (const float*)(cur + 2 * I::TILE);
     const float* delv = lsev + 64;
 
