@@ -13,10 +13,11 @@
 // once, the gradient wrt the low-res scores is accumulated in an LDS mirror of the footprint and flushed with one fp32 atomic
 // add per footprint element — 256-byte contiguous segments, the shape global float atomics run at full rate.  HBM traffic:
 // the low-res scores and labels once, the low-res gradient once.
-//  * S == 4 (the headline bicubic head and config 5's bilinear score map): head_ce_s4_kernel — 4x4-pixel groups as two small
-//    products on the fp32 matrix pipe, softmax in the accumulator layout, waves taking turns to add their gradient tiles to the
-//    LDS mirror (no LDS atomics: they retire about one lane per three cycles per CU and were 90 % of the first S = 4 kernel).
-//  * other S: head_ce_kernel — each wave walks 64 output pixels with the 64 lanes spread over CHANNELS (3 per lane, C <= 192),
+//  * S = 4, 8, 16 (the headline bicubic x4 head, config 5's bilinear x4 score map, AuxiliaryLoss at 32 -> 512): head_ce_grp_kernel —
+//    S x S-pixel groups in units of 16 pixels as two small products on the fp32 matrix pipe, softmax in the accumulator layout,
+//    waves taking turns to add their gradient tiles to the LDS mirror (no LDS atomics: they retire about one lane per three
+//    cycles per CU and were 90 % of the first S = 4 kernel).
+//  * other S (multiples of 16 from 32): head_ce_kernel — each wave walks 64 output pixels with the 64 lanes spread over CHANNELS (3 per lane, C <= 192),
 //    wave reductions for the softmax, ds_add_f32 for the gradient scatter.
 #include "common.h"
 #include "lc2is_hip.h"
@@ -210,23 +211,23 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_ce_kernel(HeadArgs p) {
   }
 }
 
-// ---- fast path: S == 4, bicubic (the headline configuration) or bilinear (config-5 score map, AuxiliaryLoss) ----
-// For S = 4 the output pixels Y in [4a+2, 4a+6) share one tap row set {a-1..a+2} and differ only in the fractional
-// weights t in {1/8, 3/8, 5/8, 7/8}; tiles are shifted by 2 pixels so they hold exactly 4x4 such GROUPS of 4x4 pixels.
-// A group is two small matrix products on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32: an exact k-ordered fp32 fma chain
-// at twice the plain-VALU rate, beside the VALU instead of on it):
+// ---- S = 4 / 8 / 16, bicubic (S = 4: the headline configuration) or bilinear (config-5 score map, AuxiliaryLoss) ----
+// The output pixels Y in [S a + S/2, S a + 3S/2) share one tap row set {a-1..a+2} (bilinear: {a, a+1}) and differ only in the
+// fractional weight t = (ph + 1/2) / S, ph = 0..S-1; tiles are shifted by S/2 pixels so that they hold exactly (16/S)^2 such GROUPS
+// of S x S pixels.  A group is worked in UNITS of 16 pixels (S = 4: the whole 4x4 group; S = 8: two rows of 8; S = 16: one row), two
+// units per wave, and a unit is two small matrix products on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32: an exact k-ordered fp32
+// fma chain at twice the plain-VALU rate, beside the VALU instead of on it):
 //   logits[16 pixels][C]  = Wm[16 pixels][NT*NT cells] x lo[cells][C]            (forward,  A = weights, B = LDS footprint)
-//   dlo   [cells][C]     += Wm^T[cells][16 pixels]     x dlogits[16 pixels][C]   (backward, B = the forward's accumulators)
+//   dlo^T [C][cells]     += dlogits^T[C][16 pixels]    x Wm[16 pixels][cells]    (backward, A = the forward's accumulators)
 // Wm[pixel (py,px)][cell (i,j)] = w(py,i) * w(px,j).  The accumulator of a 16-channel tile holds, per lane, channel
-// 16t + (lane & 15) of the four pixels (py = lane >> 4, px = 0..3): the softmax over channels is an in-lane loop over the
-// tiles plus four DPP steps inside a 16-lane row, for four pixels at once, and the same registers (now dlogits) are the B
-// operand of the backward product once its A operand is ordered to match (k = lane >> 4 <-> pixel (k, jj) in product jj).
-// The label's own terms — logit[label] for the loss, -gscale * Wm for the gradient — are 16 x NT*NT scalars per group and
-// go through LDS reads / LDS adds with one (pixel, cell quad) per lane.
-// Bilinear uses the same grouping with 2 taps {a, a+1} and weights {1-t, t} (one product of k = 4 per tile); torch's clamp
-// of the source coordinate at 0 equals clamping the tap indices because the two clamped taps then coincide.
-template <int MODE> __device__ __forceinline__ float tap_w(int ph, int k) {
-  const float t = 0.125f + 0.25f * (float)ph;
+// 16t + (lane & 15) of the four pixels 4 (lane >> 4) + r of the unit: the softmax over channels is an in-lane loop over the
+// tiles plus four DPP steps inside a 16-lane row, for four pixels at once, and the same registers (now dlogits) are the A
+// operand of the backward product once its B operand is ordered to match (k = lane >> 4 <-> pixel 4 k + jj in product jj).
+// The label's logit (for the loss) is 16 x NT*NT scalars per unit: LDS reads with one (pixel, cell quad) per lane; its one-hot
+// is subtracted from dlogits in the accumulator layout.
+// Bilinear's clamp of the source coordinate at 0 (torch) equals clamping the tap indices because the two clamped taps coincide.
+template <int MODE, int S> __device__ __forceinline__ float tap_w(int ph, int k) {
+  const float t = ((float)ph + 0.5f) * (1.f / (float)S);
   if constexpr (MODE == LC2IS_INTERP_BICUBIC)
     return k == 0 ? cubic2(t + 1.f) : (k == 1 ? cubic1(t) : (k == 2 ? cubic1(1.f - t) : cubic2(2.f - t)));
   else
@@ -245,18 +246,25 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v + row_dpp<0x140>(v);
 }
 
-template <int MODE, int TN>
-__global__ __launch_bounds__(HEAD_THREADS, 2) void head_ce_s4_kernel(HeadArgs p) {
+constexpr int head_grp_footprint(int mode, int S) { return HT / S + (mode == LC2IS_INTERP_BICUBIC ? 4 : 2) - 1; }
+
+template <int MODE, int TN, int S>
+__global__ __launch_bounds__(HEAD_THREADS, (S == 4 ? 2 : 1)) void head_ce_grp_kernel(HeadArgs p) {
   constexpr int NT = (MODE == LC2IS_INTERP_BICUBIC) ? 4 : 2;   // taps per axis
   constexpr int OFF = (MODE == LC2IS_INTERP_BICUBIC) ? 1 : 0;  // first tap = a - OFF
-  constexpr int F4 = 4 + NT - 1;                               // footprint edge: 4 groups + NT - 1
+  constexpr int G = HT / S;                                    // groups per tile edge
+  constexpr int F4 = G + NT - 1;                               // footprint edge
   constexpr int NQ = NT * NT / 4;                              // k = 4 chunks of the forward product
+  constexpr int UPG = S * S / 16;                              // 16-pixel units per group (whole rows of the group: 16 / S rows each)
+  constexpr bool SUMD = UPG > 1;                               // a wave's two units belong to one group: their gradient tiles are summed
+  static_assert(S == 4 || S == 8 || S == 16, "group kernel: S x S pixel groups inside a 16 x 16 tile");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int tiles_x = (p.W + 2 + HT - 1) / HT, tiles_y = (p.H + 2 + HT - 1) / HT;
+  const int tiles_x = (p.W + S / 2 + HT - 1) / HT, tiles_y = (p.H + S / 2 + HT - 1) / HT;
   const int b = blockIdx.x / (tiles_x * tiles_y);
   const int tyi = (blockIdx.x / tiles_x) % tiles_y, txi = blockIdx.x % tiles_x;
-  const int a0 = 4 * tyi - 1, b0 = 4 * txi - 1;  // "floor" lo index of the tile's first group row / column
+  const int a0 = G * tyi - 1, b0 = G * txi - 1;  // "floor" lo index of the tile's first group row / column
+  const int Y0 = S * a0 + S / 2, X0 = S * b0 + S / 2;   // the tile's first output pixel
   const int Cp = p.ld;
   const int CS = Cp + HEAD_PAD;                  // cell stride in LDS (floats): the 16 cells of a group on different banks
   float* s_lo = (float*)smem;
@@ -273,7 +281,7 @@ __global__ __launch_bounds__(HEAD_THREADS, 2) void head_ce_s4_kernel(HeadArgs p)
     if (p.dlo) *reinterpret_cast<float4*>(s_dlo + cell * CS + c) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   if (tid < HT * HT) {
-    const int Y = 4 * a0 + 2 + (tid >> 4), X = 4 * b0 + 2 + (tid & 15);
+    const int Y = Y0 + (tid >> 4), X = X0 + (tid & 15);
     int code = -2;
     if (Y >= 0 && X >= 0 && Y < p.H && X < p.W) {
       code = -1;
@@ -289,30 +297,45 @@ __global__ __launch_bounds__(HEAD_THREADS, 2) void head_ce_s4_kernel(HeadArgs p)
   const int m = lane & 15, kq = lane >> 4;
   const float NEG = -__builtin_inff();
   constexpr float LOG2E = 1.4426950408889634f;
-  // forward A: row = pixel m (py = m >> 2, px = m & 3), k = kq -> cell 4q + kq.  Backward (transposed: rows = channels, columns =
-  // cells) B of product jj: column = cell m, k = kq -> pixel (py = kq, px = jj)
-  float Af[NQ], Bb[4];
-  int cell_off[NQ];   // LDS float offset of the forward cell, relative to the group's first cell
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    const int c = 4 * q + kq, i = c / NT, j = c % NT;
-    Af[q] = tap_w<MODE>(m >> 2, i) * tap_w<MODE>(m & 3, j);
-    cell_off[q] = (i * F4 + j) * CS;
-  }
-#pragma unroll
-  for (int jj = 0; jj < 4; ++jj) Bb[jj] = (m < NT * NT) ? tap_w<MODE>(kq, m / NT) * tap_w<MODE>(jj, m % NT) : 0.f;
   const int cellm_off = ((m / NT) * F4 + m % NT) * CS + 4 * kq;   // this lane's cell / channel quad in the transposed gradient tile
+  int cell_off[NQ];   // LDS float offset of the forward cell 4q + kq, relative to the group's first cell
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) cell_off[q] = (((4 * q + kq) / NT) * F4 + (4 * q + kq) % NT) * CS;
+  // forward A: row = pixel m of the unit, k = kq -> cell 4q + kq.  Backward B of product jj: column = cell m, k = kq -> pixel 4 kq + jj
+  float Af[NQ], Bb[4];
+  auto make_operands = [&](int prow) {
+    const int py_m = prow + m / S, px_m = m % S;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) Af[q] = tap_w<MODE, S>(py_m, (4 * q + kq) / NT) * tap_w<MODE, S>(px_m, (4 * q + kq) % NT);
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int n = 4 * kq + jj;
+      Bb[jj] = (m < NT * NT) ? tap_w<MODE, S>(prow + n / S, m / NT) * tap_w<MODE, S>(n % S, m % NT) : 0.f;
+    }
+  };
+  if constexpr (!SUMD) make_operands(0);
   float loss_acc = 0.f, cnt_acc = 0.f;
+  f32x4_t dsum[SUMD ? TN : 1];
+  if constexpr (SUMD) {
+#pragma unroll
+    for (int t = 0; t < TN; ++t) dsum[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  bool have_d = false;
+  int gbase = 0;
 
 #pragma unroll 1
   for (int g2 = 0; g2 < 2; ++g2) {
-    const int gi = 2 * wid + g2, gy = gi >> 2, gx = gi & 3;
-    const int Yb = 4 * (a0 + gy) + 2, Xb = 4 * (b0 + gx) + 2;
-    const bool active = !(Yb >= p.H || Xb >= p.W || Yb + 3 < 0 || Xb + 3 < 0);  // wave-uniform
-    const int gbase = (gy * F4 + gx) * CS;
-    f32x4_t acc[TN];   // logits, then exp, then (as d) the transposed gradient tiles
-    bool have_d = false;
+    const int u = 2 * wid + g2, gi = u / UPG, rt = u % UPG, gy = gi / G, gx = gi % G;
+    const int Yb = Y0 + S * gy, Xb = X0 + S * gx;   // the group's first output pixel
+    // pixel n of the unit: (py, px) inside the group
+    const int prow = rt * (16 / S);
+    const bool active = !(Yb + prow >= p.H || Xb >= p.W || Yb + prow + 16 / S - 1 < 0 || Xb + S - 1 < 0);  // wave-uniform
+    gbase = (gy * F4 + gx) * CS;
+    f32x4_t acc[TN];   // logits, then exp, then (S = 4: in place) the transposed gradient tiles
+    if constexpr (!SUMD) have_d = false;
     if (active) {
+      const int py_m = prow + m / S, px_m = m % S;
+      if constexpr (SUMD) make_operands(prow);   // (S = 4: one unit shape, formed once in front of the loop)
 #pragma unroll
       for (int t = 0; t < TN; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -324,15 +347,16 @@ __global__ __launch_bounds__(HEAD_THREADS, 2) void head_ce_s4_kernel(HeadArgs p)
 #pragma unroll
         for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(Af[q], bv[t], acc[t], 0, 0, 0);
       }
-      // this lane's four accumulator pixels: (py = kq, px = 0..3)
-      const i32x4_t lab4 = *reinterpret_cast<const i32x4_t*>(s_lab + (4 * gy + kq) * 16 + 4 * gx);
+      // this lane's four accumulator pixels 4 kq .. 4 kq + 3 of the unit: one row of the tile, four consecutive columns
+      const int py4 = prow + (4 * kq) / S, px4 = (4 * kq) % S;
+      const i32x4_t lab4 = *reinterpret_cast<const i32x4_t*>(s_lab + (S * gy + py4) * 16 + S * gx + px4);
       if (p.hi_out) {
         const size_t plane = (size_t)p.H * p.W;
 #pragma unroll
         for (int t = 0; t < TN; ++t) {
           const int ch = 16 * t + m;
           if (ch < p.C) {
-            float* o = p.hi_out + ((size_t)b * p.C + ch) * plane + (size_t)(Yb + kq) * p.W + Xb;
+            float* o = p.hi_out + ((size_t)b * p.C + ch) * plane + (size_t)(Yb + py4) * p.W + Xb + px4;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
               if (lab4[r] != -2) o[r] = acc[t][r];
@@ -341,7 +365,7 @@ __global__ __launch_bounds__(HEAD_THREADS, 2) void head_ce_s4_kernel(HeadArgs p)
       }
       if (p.loss_sum) {
         // the label's logit: this lane owns pixel m x cells {4q + kq}
-        const int lab_m = s_lab[(4 * gy + (m >> 2)) * 16 + 4 * gx + (m & 3)];
+        const int lab_m = s_lab[(S * gy + py_m) * 16 + S * gx + px_m];
         if (lab_m >= 0) {
 #pragma unroll
           for (int q = 0; q < NQ; ++q) loss_acc -= Af[q] * s_lo[gbase + cell_off[q] + lab_m];
@@ -387,21 +411,22 @@ __global__ __launch_bounds__(HEAD_THREADS, 2) void head_ce_s4_kernel(HeadArgs p)
 #pragma unroll
             for (int r = 0; r < 4; ++r) gv[r] = acc[t][r] * inv[r] - (dl[r] == 16 * t ? p.gscale : 0.f);
             f32x4_t d = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (SUMD) d = dsum[t];
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) d = __builtin_amdgcn_mfma_f32_16x16x4f32(gv[jj], Bb[jj], d, 0, 0, 0);
-            acc[t] = d;   // d[r] = channel 16 t + 4 kq + r of cell m
+            if constexpr (SUMD) dsum[t] = d; else acc[t] = d;   // d[r] = channel 16 t + 4 kq + r of cell m
           }
         }
       }
     }
-    // The 16 groups of a tile overlap in every footprint cell (bicubic), and LDS float atomics retire about one LANE per three
-    // cycles per CU — 2 800 lane-adds per group made them 90 % of this kernel.  The waves take turns instead: plain 16-byte
-    // read-add-write of the transposed tiles (one cell per lane, four consecutive channels, conflict-free under the padded stride).
-    // Bilinear footprints are 2 x 2 cells: the groups a pass runs on waves of equal (wid >> 1) & 1 sit two cells apart in both
-    // directions, so two turns per pass do.
-    if (p.dlo) {
-      constexpr int NTURN = (MODE == LC2IS_INTERP_BICUBIC) ? HEAD_THREADS / 64 : 2;
-      const int my_turn = (MODE == LC2IS_INTERP_BICUBIC) ? wid : ((wid >> 1) & 1);
+    // The groups of a tile overlap in every footprint cell (bicubic), and LDS float atomics retire about one LANE per three
+    // cycles per CU — 2 800 lane-adds per group made them 90 % of the first S = 4 kernel.  The waves take turns instead: plain
+    // 16-byte read-add-write of the transposed tiles (one cell per lane, four consecutive channels, conflict-free under the padded
+    // stride).  S = 4 bilinear footprints are 2 x 2 cells: the groups a pass runs on waves of equal (wid >> 1) & 1 sit two cells
+    // apart in both directions, so two turns per pass do.  S >= 8: a wave's two units are one group's, one round of turns per tile.
+    if (p.dlo && (!SUMD || g2 == 1)) {
+      constexpr int NTURN = (S == 4 && MODE != LC2IS_INTERP_BICUBIC) ? 2 : HEAD_THREADS / 64;
+      const int my_turn = (S == 4 && MODE != LC2IS_INTERP_BICUBIC) ? ((wid >> 1) & 1) : wid;
       for (int turn = 0; turn < NTURN; ++turn) {
         __syncthreads();
         if (turn == my_turn && have_d && m < NT * NT) {
@@ -409,7 +434,7 @@ __global__ __launch_bounds__(HEAD_THREADS, 2) void head_ce_s4_kernel(HeadArgs p)
 #pragma unroll
           for (int t = 0; t < TN; ++t) {
             f32x4_t v = *reinterpret_cast<f32x4_t*>(dp + 16 * t);
-            v += acc[t];
+            if constexpr (SUMD) v += dsum[t]; else v += acc[t];
             *reinterpret_cast<f32x4_t*>(dp + 16 * t) = v;
           }
         }
@@ -575,33 +600,38 @@ extern "C" int lc2is_head_upsample_ce(const float* scores_lo, int ld, const int6
       return LC2IS_ERR_LAUNCH;
     attr_set = true;
   }
-  if (S == 4) {
+  if (S == 4 || S == 8 || S == 16) {
     // channel tiles of 16 the kernel runs (tiles past C are masked): the smallest instantiation that covers C inside the row stride
     const int nt = (C + 15) / 16;
     const int tn = nt <= 4 ? 4 : (nt <= 8 ? 8 : (nt <= 10 ? 10 : 12));
-    const int f4 = (mode == LC2IS_INTERP_BICUBIC) ? 7 : 5;
+    const int f4 = head_grp_footprint(mode, S);
     const int lds4 = 2 * f4 * f4 * (ld + HEAD_PAD) * (int)sizeof(float) + HT * HT * (int)sizeof(int);
-    const int t4 = ((H + 2 + HT - 1) / HT) * ((W + 2 + HT - 1) / HT);
-#define LC2IS_HEAD_S4(MODE_, TN_)                                                                                            \
+    const int t4 = ((H + S / 2 + HT - 1) / HT) * ((W + S / 2 + HT - 1) / HT);
+#define LC2IS_HEAD_GRP(MODE_, TN_, S_)                                                                                       \
   do {                                                                                                                      \
     static bool attr = false;                                                                                               \
     if (!attr) {                                                                                                            \
-      if (hipFuncSetAttribute((const void*)head_ce_s4_kernel<MODE_, TN_>, hipFuncAttributeMaxDynamicSharedMemorySize,       \
+      if (hipFuncSetAttribute((const void*)head_ce_grp_kernel<MODE_, TN_, S_>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                               2 * 7 * 7 * (CMAX + HEAD_PAD) * (int)sizeof(float) + HT * HT * (int)sizeof(int)) != hipSuccess) \
         return LC2IS_ERR_LAUNCH;                                                                                            \
       attr = true;                                                                                                          \
     }                                                                                                                       \
-    hipLaunchKernelGGL((head_ce_s4_kernel<MODE_, TN_>), dim3(B * t4), dim3(HEAD_THREADS), lds4, stream, a);                 \
+    hipLaunchKernelGGL((head_ce_grp_kernel<MODE_, TN_, S_>), dim3(B * t4), dim3(HEAD_THREADS), lds4, stream, a);            \
   } while (0)
-#define LC2IS_HEAD_S4_MODE(MODE_)                                                                                           \
+#define LC2IS_HEAD_GRP_TN(MODE_, S_)                                                                                         \
   do {                                                                                                                      \
-    if (tn == 4) LC2IS_HEAD_S4(MODE_, 4); else if (tn == 8) LC2IS_HEAD_S4(MODE_, 8);                                        \
-    else if (tn == 10) LC2IS_HEAD_S4(MODE_, 10); else LC2IS_HEAD_S4(MODE_, 12);                                             \
+    if (tn == 4) LC2IS_HEAD_GRP(MODE_, 4, S_); else if (tn == 8) LC2IS_HEAD_GRP(MODE_, 8, S_);                               \
+    else if (tn == 10) LC2IS_HEAD_GRP(MODE_, 10, S_); else LC2IS_HEAD_GRP(MODE_, 12, S_);                                    \
   } while (0)
-    if (mode == LC2IS_INTERP_BICUBIC) LC2IS_HEAD_S4_MODE(LC2IS_INTERP_BICUBIC);
-    else LC2IS_HEAD_S4_MODE(LC2IS_INTERP_BILINEAR);
-#undef LC2IS_HEAD_S4_MODE
-#undef LC2IS_HEAD_S4
+#define LC2IS_HEAD_GRP_S(MODE_)                                                                                              \
+  do {                                                                                                                      \
+    if (S == 4) LC2IS_HEAD_GRP_TN(MODE_, 4); else if (S == 8) LC2IS_HEAD_GRP_TN(MODE_, 8); else LC2IS_HEAD_GRP_TN(MODE_, 16); \
+  } while (0)
+    if (mode == LC2IS_INTERP_BICUBIC) LC2IS_HEAD_GRP_S(LC2IS_INTERP_BICUBIC);
+    else LC2IS_HEAD_GRP_S(LC2IS_INTERP_BILINEAR);
+#undef LC2IS_HEAD_GRP_S
+#undef LC2IS_HEAD_GRP_TN
+#undef LC2IS_HEAD_GRP
     return lc2is_check_launch();
   }
   const int tiles = ((H + HT - 1) / HT) * ((W + HT - 1) / HT);

@@ -126,7 +126,9 @@ def test_optimizers(dev):
 @pytest.mark.parametrize("B,h,C,S,mode", [(2, 32, 151, 4, "bicubic"), (1, 8, 151, 4, "bicubic"),
                                           (2, 8, 150, 16, "bilinear"), (1, 16, 37, 8, "bilinear"),
                                           (1, 12, 151, 4, "bicubic"), (2, 32, 150, 4, "bilinear"),
-                                          (1, 5, 150, 4, "bilinear"), (1, 8, 10, 4, "bilinear")])
+                                          (1, 5, 150, 4, "bilinear"), (1, 8, 10, 4, "bilinear"),
+                                          (1, 16, 151, 8, "bicubic"), (2, 8, 21, 16, "bicubic"), (1, 7, 150, 8, "bilinear"),
+                                          (1, 3, 150, 16, "bilinear"), (1, 4, 50, 32, "bilinear")])
 def test_head_upsample_ce(dev, B, h, C, S, mode):
     from lc2is_amd import ops
     g = torch.Generator(device="cpu").manual_seed(h + C)
@@ -160,6 +162,32 @@ def test_head_upsample_ce(dev, B, h, C, S, mode):
     assert abs(loss2[0].item() - rl2.item()) < 1e-4 * abs(rl2.item())
     assert int(loss2[1].item()) == int((labels2 != 0).sum().item())
     assert _rel(dlo2[:, :C], lod.grad.permute(0, 2, 3, 1).reshape(B * h * h, C)) < 2e-5
+
+
+@pytest.mark.parametrize("S,mode", [(4, "bicubic"), (8, "bilinear"), (16, "bicubic")])
+def test_head_upsample_ce_rectangular(dev, S, mode):
+    """h != w, sizes that leave ragged tiles on both edges; ignore_index = -100 rows; loss, gradient, upsampled scores vs fp64 torch"""
+    from lc2is_amd import ops
+    B, h, w, C = 2, 5, 11, 151
+    g = torch.Generator(device="cpu").manual_seed(S)
+    lo = torch.zeros(B * h * w, 192)
+    lo[:, :C] = torch.randn(B * h * w, C, generator=g) * 3
+    lo = lo.to(dev)
+    H, W = h * S, w * S
+    labels = torch.randint(0, C, (B, H, W), generator=g)
+    labels[:, 1::5] = -100
+    labels = labels.to(dev)
+    m = ops.INTERP_BICUBIC if mode == "bicubic" else ops.INTERP_BILINEAR
+    loss, dlo, hi = ops.head_upsample_ce(lo, labels, B, h, w, C, S, m, want_grad=True, want_scores=True, grad_scale=0.5)
+    lod = lo[:, :C].double().reshape(B, h, w, C).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    up = F.interpolate(lod, scale_factor=S, mode=mode)
+    assert (hi.double() - up).abs().max().item() < 5e-5
+    ref = F.cross_entropy(up, labels, reduction="sum")
+    (0.5 * ref).backward()
+    assert abs(loss[0].item() - ref.item()) < 1e-4 * abs(ref.item())
+    assert int(loss[1].item()) == int((labels != -100).sum().item())
+    assert _rel(dlo[:, :C], lod.grad.permute(0, 2, 3, 1).reshape(B * h * w, C)) < 2e-5
+    assert dlo[:, C:].abs().sum().item() == 0
 
 
 def test_ce_nchw(dev):

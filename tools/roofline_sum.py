@@ -75,7 +75,7 @@ def main():
         bws.append(bw("ln_bwd_kernel", k[1], 18.0 * M * C, "ln_bwd (vision tower, M x 768 fp32 stream)"))
     # (the fused head moves 16x fewer bytes than the literal order by design: its time is the fp32 matrix pipe + the softmax
     #  arithmetic over 151 x 16384 scores per image, not HBM — the GB/s figure is reported because SURVEY.md §8d asks for it)
-    bws.append(bw("head_ce_s4", None, 1.9e6 * B, "head_ce_s4 (fused bicubic x4 + CE fwd/bwd, 1.9 MB/img; compute-bound by design)"))
+    bws.append(bw("head_ce_grp", None, 1.9e6 * B, "head_ce_grp, S = 4 (fused bicubic x4 + CE fwd/bwd, 1.9 MB/img; compute-bound by design; `head_ce_s4` before round 3)"))
     bws.append(bw("sgd_kernel", None, 12.0 * 157.09e6, "sgd (157.09 M fp32 parameters: read p, g, write p)"))
     out["bandwidth_kernels"] = [b for b in bws if b]
     if pmc:
