@@ -380,13 +380,14 @@ __global__ __launch_bounds__(HEAD_THREADS, (S == 4 ? 2 : 1)) void head_ce_grp_ke
 #pragma unroll
           for (int r = 0; r < 4; ++r) mx[r] = fmaxf(mx[r], acc[t][r]);
         }
+        float mxl[4];   // -max * log2(e): exp(x - max) = exp2(fma(x, log2(e), mxl))
 #pragma unroll
-        for (int r = 0; r < 4; ++r) mx[r] = row16_max(mx[r]);
+        for (int r = 0; r < 4; ++r) { mx[r] = row16_max(mx[r]); mxl[r] = -mx[r] * LOG2E; }
 #pragma unroll
         for (int t = 0; t < TN; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float e = __builtin_amdgcn_exp2f((acc[t][r] - mx[r]) * LOG2E);
+            const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[t][r], LOG2E, mxl[r]));
             acc[t][r] = e;
             sum[r] += e;
           }
