@@ -10,7 +10,8 @@
 //   (2) dK/dV kernel — "key on the lane": a wave owns 32 keys (K, V fragments live in registers for the whole
 //       kernel), and sweeps the queries: S = Q·K^T, dP = dO·V^T, then dV^T[d][key] += dO^T·P and
 //       dK^T[d][key] += Q^T·dS take the fp32 accumulators of S/dP, packed to bf16, directly as MFMA B
-//       operands (accumulator-as-operand), so nothing but the shared Q/dO tiles touches LDS.
+//       operands (accumulator-as-operand), so nothing but the shared Q/dO tiles touches LDS (they arrive by LDS-DMA,
+//       double-buffered, like the K / V tiles of (1)).
 // The shared tiles are read BOTH by rows (ds_read_b128, MFMA A operand of S/dP) and by columns
 // (ds_read_b64_tr_b16, A operand of the transposed products) from ONE LDS image, made conflict-free for
 // both by an XOR swizzle of the 16-byte chunk index (128-byte rows for D=64, 256-byte rows otherwise).
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(256, (D == 64) ? LC2IS_DQ2_WAVES : (D <= 96 ? 2 : 1
 }
 
 // ------------------------------------------------------------------------------------------------------
-// (2) dK/dV kernel: grid (ceil(Sk/128), H, B), 4 waves x 32 keys; loops over 64-query tiles.
+// (2) dK/dV kernel: 1-D XCD-aware grid over (key block of 128, head, batch), 4 waves x 32 keys; loops over 64-query tiles.
 // ------------------------------------------------------------------------------------------------------
 template <int D, bool DROP = false>
 __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
