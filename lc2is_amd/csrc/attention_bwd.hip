@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256, (D == 64) ? LC2IS_DQ2_WAVES : (D <= 96 ? 2 : 1
     }
   };
   auto land = [&]() __attribute__((always_inline)) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_vm0();
     __builtin_amdgcn_s_barrier();
   };
 
@@ -430,20 +430,18 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(A
     if (tid < 128) {  // threads 0..63: lse2, 64..127: delta
       const int q = qt * 64 + (tid & 63);
       const size_t si = ((size_t)b * p.H + head) * p.Sq + q;
-      if (tid < 64) {
-        float l = (q < p.Sq) ? p.lse2[si] : INF;
-        rstat = (l == -INF) ? INF : l;
-      } else {
-        rstat = (q < p.Sq) ? p.delta[si] : 0.f;
-      }
+      // the RAW values: nothing may wait for these loads here (a use would drain the DMA pieces requested just above); the
+      // -inf -> +inf mapping of an empty row's log-sum-exp happens in lstore
+      const float* src = tid < 64 ? p.lse2 : p.delta;
+      rstat = (q < p.Sq) ? src[si] : (tid < 64 ? INF : 0.f);
     } else if (DROP && tid < 192) {   // 128..191: the row half of the dropout hash of query q
       const int q = qt * 64 + (tid & 63);
       rstat = __builtin_bit_cast(float, drop_row_hash(p.drop, (unsigned)((b * p.H + head) * p.Sq + q)));
     }
   };
   auto lstore = [&](char* stage) {   // the row statistics; then every DMA piece this wave requested has landed
-    if (tid < (DROP ? 192 : 128)) *(float*)(stage + 2 * I::TILE + tid * 4) = rstat;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid < (DROP ? 192 : 128)) *(float*)(stage + 2 * I::TILE + tid * 4) = (tid < 64 && rstat == -INF) ? INF : rstat;
+    wait_vm0();
   };
 
   const int q4 = (lane >> 2) & 3, p4 = lane & 3, cg = (lane >> 4) & 1;
@@ -463,10 +461,8 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(A
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dkt[d][r] = 0.f; dvt[d][r] = 0.f; }
 
-  if (qt0 < nqt) {
-    gload(qt0, smem);
-    lstore(smem);
-  }
+  gload(qt0, smem);   // (qt0 < nqt always: a causal launch has Sq == Sk.)  Unconditional, so that hipcc sees the wait in lstore on
+  lstore(smem);       // every path into the loops and stops re-waiting for the K / V fragment loads inside them
   __syncthreads();
 
   // One tile of 64 queries.  DIAG (some key of the block may exceed some query of the tile: causal launches only) is a
@@ -553,6 +549,7 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(A
     }
     }  // wave_active
     if (more) lstore(nxt);
+    else wait_vm0();   // (keeps hipcc's vmcnt bookkeeping clean on the loop's back edge: see common.h)
     __syncthreads();
   };
   // causal launches: the first tiles (queries up to the block's last key) straddle the diagonal, the rest lie below it

@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256, (D == 64) ? 3 : 2) void attn_fwd_kernel(AttnFw
     }
   };
   auto land = [&]() __attribute__((always_inline)) {   // this wave's outstanding DMAs have landed, and behind the barrier so have every wave's
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_vm0();
     __builtin_amdgcn_s_barrier();
   };
 

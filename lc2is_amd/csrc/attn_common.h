@@ -28,18 +28,19 @@ template <int D> struct AttnCfg {
   __device__ static __forceinline__ int off(int row, int ch) { return row * PITCH + ((ch ^ swz(row)) << 4); }
 };
 
-// (the LDS-DMA builtin lives in a helper that takes no buffer-resource parameter: see gemm_nt.hip)
+// one K / V (or Q / dO) tile pair: PPW 1-KiB pieces per operand and wave, requested by inline-asm LDS-DMA (common.h: lds_dma16)
 template <int D>
 __device__ __forceinline__ void attn_dma_tile(const bf16_t* K, unsigned kbytes, const bf16_t* V, unsigned vbytes, char* stage,
                                               int wid, const int* k_goff, const int* v_goff, int kstep, int vstep) {
   using Cfg = AttnCfg<D>;
   const __amdgpu_buffer_rsrc_t rsK = make_rsrc(K, kbytes);
   const __amdgpu_buffer_rsrc_t rsV = make_rsrc(V, vbytes);
+  const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)LDS_PTR(stage));
+  const int ks = __builtin_amdgcn_readfirstlane(kstep), vs = __builtin_amdgcn_readfirstlane(vstep);
 #pragma unroll
   for (int j = 0; j < Cfg::PPW; ++j) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, LDS_PTR(stage + (wid * Cfg::PPW + j) * 1024), 16, k_goff[j], kstep, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, LDS_PTR(stage + Cfg::TILE + (wid * Cfg::PPW + j) * 1024), 16, v_goff[j], vstep,
-                                             0, 0);
+    lds_dma16(rsK, base + (wid * Cfg::PPW + j) * 1024, k_goff[j], ks);
+    lds_dma16(rsV, base + Cfg::TILE + (wid * Cfg::PPW + j) * 1024, v_goff[j], vs);
   }
 }
 

@@ -43,6 +43,40 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
 
+// LDS-DMA (buffer_load_dwordx4 ... lds: 64 lanes x 16 bytes land at LDS address `lds_addr` + 16 * lane, no VGPR destination) issued
+// by inline asm.  Why not __builtin_amdgcn_raw_ptr_buffer_load_lds: hipcc's waitcnt insertion treats the builtin as a pending LDS
+// WRITE and puts `s_waitcnt vmcnt(..)` in front of every later LDS read it cannot prove disjoint from it — vmcnt(0) before each
+// ds_read_b64_tr_b16 group, vmcnt(6..7) before MFMAs fed by ds_read_b128 — so a DMA ring requested "two tiles ahead" was drained a
+// few instructions after every request (found in round 4 in the ISA of all three attention kernels: the tile's HBM / L2 latency sat
+// exposed in every tile).  Through asm the compiler does not see the LDS write; every consumer already waits by hand
+// (`s_waitcnt vmcnt(N)` + barrier before the first read of a landed tile).  The compiler's own counted waits for ordinary loads
+// stay correct: it does not count these DMAs, so it can only wait for MORE than it needs.
+// lds_addr must be wave-uniform (it goes to M0, saved and restored around the request); `s_nop 3` + the two s_mov cover the
+// VALU-written-SGPR -> VMEM hazard of operands that come fresh from v_readfirstlane.
+__device__ __forceinline__ void lds_dma16(const __amdgpu_buffer_rsrc_t rsrc, unsigned lds_addr, int voffset, int soffset) {
+  unsigned keep;
+  lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);   // (uniform by contract; this makes it provable)
+  soffset = __builtin_amdgcn_readfirstlane(soffset);
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %1\n\t"
+      "s_nop 3\n\t"
+      "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "s"(lds_addr), "v"(voffset), "s"(rsrc), "s"(soffset)
+      : "memory");
+}
+
+// Every outstanding vector-memory operation of this wave has completed (inline-asm LDS-DMAs included).  The asm statement is
+// the ordering point for the compiler's memory operations; the builtin repeats the wait in a form hipcc's waitcnt pass can see, so
+// that it stops tracking its own earlier loads as pending — otherwise it re-waits for them with small counts (vmcnt(3..0)) inside
+// the loops, which drains the DMA pieces requested since.
+__device__ __forceinline__ void wait_vm0() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
+}
+
 // Wave64 reductions as DPP row ops (quad_perm x2, row_half_mirror, row_mirror), row_bcast:15 / row_bcast:31 into the
 // upper rows and a v_readlane of lane 63: 6 VALU-rate ops and a uniform (SGPR) result.  The __shfl_xor butterfly
 // lowers to six ds_bpermute_b32 (an LDS-pipe round trip each) on gfx950 - tools/probes/wave_reduce.hip.
