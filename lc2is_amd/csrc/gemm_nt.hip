@@ -696,6 +696,177 @@ __global__ __launch_bounds__(512) void gemm_nt_persist2_kernel(GemmNtArgs p, int
   }
 }
 
+// ---- persistent form with the two wave groups in PING-PONG (cfg 15) ------------------------------------------------------------
+// Same tile algebra, epilogue and seam as cfg 13 (bitwise equal to cfg 4), but the K step is no longer executed by all eight
+// waves in lockstep ("everybody issues DMA pieces — no MFMA in flight for ~960 cycles —, everybody runs 64 MFMAs on a matrix pipe
+// shared with its SIMD partner, everybody waits at the barrier": profiles/r03_gemm_step_stamps.txt, 3440 cycles per K step for
+// 2048 cycles of matrix pipe).  The two groups of four waves (wm = 0 / 1; the partners on a SIMD are waves w and w + 4) run HALF
+// A K STEP apart, two barriers per K step: while one group is in its COMPUTE segment (24 fragment reads, 64 MFMAs — alone on
+// the matrix pipe), the other is in its LOAD segment (inline-asm LDS-DMA requests, counted wait).  With two K-tile buffers:
+//   group 0, load segment t:    request its OWN half of A (rows 0..127: only group 0 reads them) of K tile t+1; await A(t)
+//   group 1, load segment t:    request W (all 256 rows) and its own half of A of K tile t+1; await its A(t);
+//            compute segment t: at the end await W(t+1) — the barrier that closes the segment publishes it to group 0
+// W(t+1) may only be requested once BOTH groups have left K tile t-1 (same buffer), i.e. in group 1's load segment; a group's
+// own A half is free one interval earlier.  Waits are counted (`s_waitcnt vmcnt(n)`, n from sequence numbers, so the previous
+// epilogue's stores in the in-order queue are waited PAST, not for); nothing waits for vmcnt(0) in the steady state.
+__device__ __forceinline__ void wait_vmcnt_le(int n) {   // s_waitcnt vmcnt(<= n): even counts up to 56 (a smaller count only waits longer)
+  if (n >= 56) { asm volatile("s_waitcnt vmcnt(56)" ::: "memory"); return; }
+  switch (n >> 1) {
+#define LC2IS_W(k) case k: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * k) : "memory"); break;
+    LC2IS_W(0) LC2IS_W(1) LC2IS_W(2) LC2IS_W(3) LC2IS_W(4) LC2IS_W(5) LC2IS_W(6) LC2IS_W(7) LC2IS_W(8) LC2IS_W(9) LC2IS_W(10)
+    LC2IS_W(11) LC2IS_W(12) LC2IS_W(13) LC2IS_W(14) LC2IS_W(15) LC2IS_W(16) LC2IS_W(17) LC2IS_W(18) LC2IS_W(19) LC2IS_W(20)
+    LC2IS_W(21) LC2IS_W(22) LC2IS_W(23) LC2IS_W(24) LC2IS_W(25) LC2IS_W(26) LC2IS_W(27)
+#undef LC2IS_W
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+__device__ __forceinline__ bf16x8_t lds_read_b128(unsigned addr) {   // by 32-bit LDS address (base register + immediate offset)
+  return *(const __attribute__((address_space(3))) bf16x8_t*)(size_t)addr;
+}
+
+template <int ACT>
+__global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmNtArgs p, int ntiles) {
+  constexpr int BM = 256, BN = 256, WAVES_N = 4, BK = 64;
+  constexpr int WM = 128, WN = 64, TM = 8, TN = 4;
+  constexpr int STAGE = (BM + BN) * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int lane0 = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+  const int ntn = (p.N + BN - 1) / BN;
+  const unsigned a_bytes = (unsigned)p.M * (unsigned)p.lda * 2u, w_bytes = (unsigned)p.N * (unsigned)p.ldw * 2u;
+  const int nk = p.K / BK;
+  constexpr bool kAuxOut = ACT == LC2IS_ACT_QUICK_GELU || ACT == LC2IS_ACT_RELU || ACT == LC2IS_ACT_QUICK_GELU_GRAD ||
+                           ACT == LC2IS_ACT_GELU_ERF;
+  constexpr bool kAuxIn = ACT == LC2IS_ACT_DQUICK_GELU || ACT == LC2IS_ACT_DRELU || ACT == LC2IS_ACT_MUL_AUX || ACT == LC2IS_ACT_DGELU_ERF;
+  const int nstores = ((p.out_bf16 ? 1 : 0) + ((kAuxOut && p.aux_out) ? 1 : 0)) * (kAuxIn ? 8 : 16);   // (see cfg 13)
+  const unsigned smem_a = (unsigned)(size_t)LDS_PTR(smem);
+
+  int issued = 0;                    // DMA pieces + counted stores this wave has issued so far
+  int seq_a[2] = {0, 0}, seq_w[2] = {0, 0};   // `issued` right after the requests of a K tile's A pieces / W pieces, per buffer
+  int a_goff[4], w_goff[8];
+  auto tile_offsets = [&](int tt, int lane) {
+    const int tile = xcd_remap(tt, ntiles);
+    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+    const int lrow = lane >> 3, lch = (lane & 7) ^ (lane >> 3);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a_goff[j] = ((m0 + 8 * (wid * 4 + j) + lrow) * p.lda + lch * 8) * 2;   // pieces 4 wid .. 4 wid + 3: rows of this group's half
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w_goff[j] = ((n0 + 8 * (wn * 8 + j) + lrow) * p.ldw + lch * 8) * 2;    // (group 1 only) pieces 8 wn .. 8 wn + 7
+  };
+  auto issue_a = [&](int kt) __attribute__((always_inline)) {
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.A, a_bytes);
+    const unsigned base = smem_a + (kt & 1) * STAGE + wid * 4096;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) lds_dma16(rs, base + j * 1024, a_goff[j], kt * BK * 2);
+    issued += 4;
+    seq_a[kt & 1] = issued;
+  };
+  auto issue_w = [&](int kt) __attribute__((always_inline)) {
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.W, w_bytes);
+    const unsigned base = smem_a + (kt & 1) * STAGE + BM * 128 + wn * 8192;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) lds_dma16(rs, base + j * 1024, w_goff[j], kt * BK * 2);
+    issued += 8;
+    seq_w[kt & 1] = issued;
+  };
+
+  int t = blockIdx.x;
+  if (t >= ntiles) return;
+  tile_offsets(t, lane0);
+  if (wm == 1) issue_w(0);
+  issue_a(0);
+
+  for (;;) {
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int tile = xcd_remap(t, ntiles);
+    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+    const int frow = lane & 15, g = lane >> 4, sw = lane & 7;
+    const unsigned x_frag = smem_a + (wm * WM + frow) * 128;
+    const unsigned w_frag = smem_a + BM * 128 + (wn * WN + frow) * 128;
+    const int kc_off0 = ((0 + g) ^ sw) << 4, kc_off1 = ((4 + g) ^ sw) << 4;
+
+    wait_vmcnt_le(issued - seq_a[0]);   // this wave's pieces of K tile 0 (A is requested last) — past the previous epilogue's stores
+    __builtin_amdgcn_s_barrier();       // K tile 0 is published; every wave has left the previous tile's patches (they overlay buffer 1)
+    f32x4_t acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    if (wm == 1) __builtin_amdgcn_s_barrier();   // the second group runs one barrier (half a K step) behind
+    for (int kt = 0; kt < nk; ++kt) {
+      const bool more_k = kt + 1 < nk, steady = kt >= 1 && more_k;
+      // ---- load segment ----
+      if (more_k) {
+        if (wm == 1) issue_w(kt + 1);   // (W first: it is awaited first)
+        issue_a(kt + 1);
+      }
+      if (steady) {                     // this group's A(kt) pieces have landed; only the requests just made stay in flight
+        if (wm == 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else {
+        wait_vmcnt_le(issued - seq_a[kt & 1]);
+      }
+      __builtin_amdgcn_s_barrier();     // (for group 0 this barrier also publishes W(kt): group 1 awaited it one segment ago)
+      // ---- compute segment: alone on the matrix pipe (the SIMD partner is in its load segment) ----
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned bo = (kt & 1) * STAGE;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int ko = ks ? kc_off1 : kc_off0;
+        bf16x8_t xf[TM], wf[TN];
+#pragma unroll
+        for (int j = 0; j < TM; ++j) xf[j] = lds_read_b128(x_frag + bo + j * 2048 + ko);
+#pragma unroll
+        for (int i = 0; i < TN; ++i) wf[i] = lds_read_b128(w_frag + bo + i * 2048 + ko);
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (wm == 1 && more_k) {          // W(kt+1) has landed (its A pieces may still fly): the barrier publishes it to group 0
+        if (kt >= 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else wait_vmcnt_le(issued - seq_w[(kt + 1) & 1]);
+      }
+      __builtin_amdgcn_s_barrier();
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();   // group 1's last compute segment: the groups meet again
+
+    t += gridDim.x;
+    const bool more = t < ntiles;
+    int lane_e = lane0;
+    asm volatile("" : "+v"(lane_e));
+    // buffer 0 is free (every wave is past its last fragment read): the next tile's K tile 0 is requested from inside the
+    // epilogue, behind its last global load; the patches overlay buffer 1 (+ 9 KiB)
+    gemm_epilogue_lds_act<ACT, TM, TN, WM, WN, true>(p, acc, m0, n0, wm, wn, lane_e, wid, smem + STAGE, [&]() {
+      if (more) {
+        tile_offsets(t, lane_e);
+        if (wm == 1) issue_w(0);
+        issue_a(0);
+      }
+    });
+    issued += nstores;
+    if (!more) break;
+  }
+}
+
+template <int ACT>
+int launch_pp_act(const GemmNtArgs& a, hipStream_t stream) {
+  constexpr int LDS = (256 + 256) * 128 + 8 * 64 * 144;
+  if (hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+    return LC2IS_ERR_LAUNCH;
+  const int ntiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
+  const int grid = ntiles < 256 ? ntiles : 256;
+  hipLaunchKernelGGL(gemm_nt_pp_kernel<ACT>, dim3(grid), dim3(512), LDS, stream, a, ntiles);
+  return lc2is_check_launch();
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 int launch_cfg(const GemmNtArgs& a, hipStream_t stream, int batch = 1) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
@@ -752,6 +923,16 @@ bool persist2_ok(const GemmNtArgs& a) {
          (!a.aux_out || (double)a.M * a.ldy * 2.0 < lim) && (!a.aux_in || (double)a.M * a.ldx * 2.0 < lim);
 }
 
+int launch_pp(const GemmNtArgs& a, hipStream_t stream) {
+  if (!persist2_ok(a)) return LC2IS_ERR_UNSUPPORTED;
+  switch (a.act) {
+    case LC2IS_ACT_QUICK_GELU: return launch_pp_act<LC2IS_ACT_QUICK_GELU>(a, stream);
+    case LC2IS_ACT_DQUICK_GELU: return launch_pp_act<LC2IS_ACT_DQUICK_GELU>(a, stream);
+    case LC2IS_ACT_NONE: return launch_pp_act<LC2IS_ACT_NONE>(a, stream);
+    default: return LC2IS_ERR_UNSUPPORTED;
+  }
+}
+
 int launch_persist2(const GemmNtArgs& a, hipStream_t stream) {
   if (!persist2_ok(a)) return LC2IS_ERR_UNSUPPORTED;
   switch (a.act) {
@@ -796,6 +977,7 @@ int launch_by_cfg(const GemmNtArgs& a_in, int cfg, hipStream_t stream) {
         default: return launch_dma<128, 128, 2, 2>(a, stream);
       }
     case 13: return launch_persist2(a, stream);
+    case 15: return launch_pp(a, stream);
     default: return LC2IS_ERR_UNSUPPORTED;
   }
 }
@@ -845,8 +1027,29 @@ extern "C" int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw
   static const bool use_persist = !(getenv("LC2IS_GEMM_PERSIST") && atoi(getenv("LC2IS_GEMM_PERSIST")) == 0);
   static const long persist_min = getenv("LC2IS_GEMM_PERSIST_MIN") ? atol(getenv("LC2IS_GEMM_PERSIST_MIN")) : 257;   // more than one round of tiles (A/B 512 -> 257: 907 -> 915 img/s)
   if (use_persist && persist2_ok(a) && (long)((M + 255) / 256) * (N / 256) >= persist_min &&
-      (act == LC2IS_ACT_NONE || act == LC2IS_ACT_QUICK_GELU || act == LC2IS_ACT_DQUICK_GELU))
-    return launch_by_cfg(a, 13, stream);
+      (act == LC2IS_ACT_NONE || act == LC2IS_ACT_QUICK_GELU || act == LC2IS_ACT_DQUICK_GELU)) {
+    // One block per CU walks tiles t, t + 256, ...: the launch lasts ceil(tiles / 256) tile times.  The ragged last <= 64 rows
+    // (B x 1025 tokens: 32 rows, i.e. one more row of N / 256 tiles) are peeled off into a small-tile launch when that saves a
+    // whole tile time: fc1 / dfc2 at M = 32 800 walk 1548 tiles = 6 rounds + 12 tiles, 1536 = exactly 6 without the 32 rows.
+    static const bool peel = !(getenv("LC2IS_GEMM_PERSIST_PEEL") && atoi(getenv("LC2IS_GEMM_PERSIST_PEEL")) == 0);
+    static const int pcfg = (getenv("LC2IS_GEMM_PP") && atoi(getenv("LC2IS_GEMM_PP")) == 0) ? 13 : 15;   // cfg 15 = the wave groups in ping-pong (round 4: 966 -> 975 img/s); LC2IS_GEMM_PP=0: cfg 13
+    const int r = M % 256;
+    const long tiles_all = (long)((M + 255) / 256) * (N / 256), tiles_main = (long)(M / 256) * (N / 256);
+    if (peel && r > 0 && r <= 64 && M > 256 && (tiles_main + 255) / 256 < (tiles_all + 255) / 256) {
+      GemmNtArgs main_part = a, tail = a;
+      main_part.M = M - r;
+      int rc = launch_by_cfg(main_part, pcfg, stream);
+      if (rc) return rc;
+      const size_t m0 = (size_t)(M - r);
+      tail.M = r;
+      tail.A = a.A + m0 * lda;
+      if (a.aux_in) tail.aux_in = a.aux_in + m0 * ldx;
+      if (a.out_bf16) tail.out_bf16 = a.out_bf16 + m0 * ldo;
+      if (a.aux_out) tail.aux_out = a.aux_out + m0 * ldy;
+      return launch_by_cfg(tail, 3, stream);
+    }
+    return launch_by_cfg(a, pcfg, stream);
+  }
   // Plenty of work: 256x256 LDS-DMA tiles, one block per CU, so time = rounds x tile cost; the ragged last <= 64 rows
   // (B x 1025 tokens: 32 rows) are peeled off into a small-tile launch when that saves a whole round of tiles.
   int best_cfg = 0, best_main = M;

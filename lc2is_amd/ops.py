@@ -439,7 +439,7 @@ def attention_bwd(q, k, v, o, do, lse2, B: int, H: int, Sq: int, Sk: int, D: int
     if dropout_p > 0.0:
         rc = _fn("lc2is_attention_bwd_dropout")(*args, float(dropout_p), int(seed), _stream())
     else:
-        # one-kernel five-product form with the ordered dQ hand-off (LC2IS_ATTN_BWD_FUSED=0: the two-launch form); its
+        # LC2IS_ATTN_BWD_FUSED=1: the one-kernel five-product form with the ordered dQ hand-off (default: the two-launch form); its
         # workspace belongs to this call's stream (the caching allocator recycles it in stream order)
         ws_bytes = _fn("lc2is_attention_bwd_fused_workspace_bytes")(B, H, Sq, Sk, D) if _ATTN_BWD_FUSED else 0
         if ws_bytes:
@@ -453,7 +453,7 @@ def attention_bwd(q, k, v, o, do, lse2, B: int, H: int, Sq: int, Sk: int, D: int
     return dq, dk, dv
 
 
-_ATTN_BWD_FUSED = os.environ.get("LC2IS_ATTN_BWD_FUSED", "1") != "0"
+_ATTN_BWD_FUSED = os.environ.get("LC2IS_ATTN_BWD_FUSED", "0") != "0"   # opt-in: measured slower than the two-launch form
 _last_fused_ws = None
 
 

@@ -121,9 +121,11 @@ def test_attention_very_negative_first_keys(dev, causal):
         assert rel < 3e-2, (name, rel)
 
 
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("B,H,Sq,Sk,D,causal,mask,packed", CASES)
-def test_attention_bwd(dev, B, H, Sq, Sk, D, causal, mask, packed):
+def test_attention_bwd(dev, B, H, Sq, Sk, D, causal, mask, packed, fused, monkeypatch):
     from lc2is_amd import ops
+    monkeypatch.setattr(ops, "_ATTN_BWD_FUSED", fused)   # both forms of the backward: two launches (default) / fused five-product kernel
     g = torch.Generator(device="cpu").manual_seed(B * 999 + Sq + D)
     if packed:
         qkv = (torch.randn(B * Sq, 3 * H * D, generator=g)).to(torch.bfloat16).to(dev)
@@ -162,7 +164,7 @@ def test_attention_bwd(dev, B, H, Sq, Sk, D, causal, mask, packed):
 @pytest.mark.parametrize("B,H,Sq,Sk,D,causal", [(4, 12, 1025, 1025, 64, False), (2, 8, 1024, 1024, 96, False),
                                                 (3, 4, 400, 400, 64, True), (1, 8, 4096, 1024, 64, False),
                                                 (2, 2, 300, 700, 128, False)])
-def test_attention_bwd_fused_reproducible_and_vs_two_launch(dev, B, H, Sq, Sk, D, causal):
+def test_attention_bwd_fused_reproducible_and_vs_two_launch(dev, B, H, Sq, Sk, D, causal, monkeypatch):
     """The fused five-product kernel (ordered dQ hand-off across the key blocks of a (batch, head)): two runs are BITWISE equal
     (fixed summation order per query tile, no float atomics) although its workgroups draw their work from ticket queues in a
     run-dependent order; and it agrees with the two-launch form (same products, dQ summed in another order) to bf16 rounding.
@@ -175,7 +177,7 @@ def test_attention_bwd_fused_reproducible_and_vs_two_launch(dev, B, H, Sq, Sk, D
     do = torch.randn(B * Sq, H * D, generator=g).to(torch.bfloat16).to(dev)
     scale = 1.0 / math.sqrt(D)
     o, lse2 = ops.attention_fwd(q, k, v, B, H, Sq, Sk, D, scale, causal=causal)
-    assert ops._ATTN_BWD_FUSED
+    monkeypatch.setattr(ops, "_ATTN_BWD_FUSED", True)
     runs = []
     for _ in range(3):
         runs.append([t.clone() for t in ops.attention_bwd(q, k, v, o, do, lse2, B, H, Sq, Sk, D, scale, causal=causal)])
@@ -183,11 +185,8 @@ def test_attention_bwd_fused_reproducible_and_vs_two_launch(dev, B, H, Sq, Sk, D
     for r in runs[1:]:
         for a, b_ in zip(runs[0], r):
             assert torch.equal(a, b_)
-    ops._ATTN_BWD_FUSED = False
-    try:
-        ref = ops.attention_bwd(q, k, v, o, do, lse2, B, H, Sq, Sk, D, scale, causal=causal)
-    finally:
-        ops._ATTN_BWD_FUSED = True
+    monkeypatch.setattr(ops, "_ATTN_BWD_FUSED", False)
+    ref = ops.attention_bwd(q, k, v, o, do, lse2, B, H, Sq, Sk, D, scale, causal=causal)
     for name, a, b_ in zip(("dq", "dk", "dv"), runs[0], ref):
         rel = ((a.double() - b_.double()).norm() / b_.double().norm()).item()
         assert rel < 6e-3, (name, rel)   # both round fp32 sums to bf16 once; dS / P are rounded to bf16 identically

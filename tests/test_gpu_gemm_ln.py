@@ -133,6 +133,36 @@ def test_gemm_nt_persistent_counted_waits_is_bitwise_equal(dev, M, N, K):
         ops.gemm_nt(a, w, bias, out_bf16=None, out_f32=True, tile_cfg=13)
 
 
+@pytest.mark.parametrize("M,N,K", [(2050, 768, 768), (300, 200, 128), (66000, 512, 64), (70, 64, 64), (32800, 768, 192),
+                                   (33000, 512, 320), (4100, 1024, 3072)])
+def test_gemm_nt_ping_pong_is_bitwise_equal(dev, M, N, K):
+    """tile_cfg 15 — the persistent kernel whose two groups of four waves run half a K step apart (one group computes alone on the
+    matrix pipe while its SIMD partners request the next K tile by inline-asm LDS-DMA; counted `s_waitcnt vmcnt(n)`, nothing waits
+    for vmcnt(0) in the steady state) — against tile_cfg 4: same accumulation order, so the outputs are bitwise equal.  K = 64 ..
+    3072 covers one K tile, two / three (only the sequence-counted waits), five (odd count: the last K tile sits in buffer 0 when
+    the next output tile's first requests go out) and 48; several output tiles per block (66000 x 512 = 516 tiles) exercise the
+    seam where the epilogue's stores sit between the DMA requests in the in-order vmcnt queue.  A wait that is too weak reads a K
+    tile before its DMA landed; a request made too early overwrites fragments the other wave group still reads."""
+    from lc2is_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    a = _bf(torch.randn(M, K, generator=g)).to(dev)
+    w = _bf(torch.randn(N, K, generator=g) * 0.1).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    saved = _bf(torch.randn(M, N, generator=g)).to(dev)
+    for rep in range(3):   # (warm caches on the later runs: a different DMA timing)
+        o4, _, _ = ops.gemm_nt(a, w, bias, tile_cfg=4)
+        o15, _, _ = ops.gemm_nt(a, w, bias, tile_cfg=15)
+        assert torch.equal(o4, o15)
+        o4, _, z4 = ops.gemm_nt(a, w, bias, act=ops.ACT_QUICK_GELU, aux_out=True, tile_cfg=4)
+        o15, _, z15 = ops.gemm_nt(a, w, bias, act=ops.ACT_QUICK_GELU, aux_out=True, tile_cfg=15)
+        assert torch.equal(o4, o15) and torch.equal(z4, z15)
+        d4, _, _ = ops.gemm_nt(a, w, None, act=ops.ACT_DQUICK_GELU, aux_in=saved, tile_cfg=4)
+        d15, _, _ = ops.gemm_nt(a, w, None, act=ops.ACT_DQUICK_GELU, aux_in=saved, tile_cfg=15)
+        assert torch.equal(d4, d15)
+    ref = a.double() @ w.double().T + bias.double()
+    assert _rel(ops.gemm_nt(a, w, bias, tile_cfg=15)[0].float(), ref) < 4e-3
+
+
 @pytest.mark.parametrize("N,K", [(3072, 128), (768, 192), (2304, 128)])
 def test_gemm_nt_auto_plan_ragged_rows(dev, N, K):
     """M = 64*256 + 32 rows (the B x 1025-token shape): the automatic plan peels the ragged rows into a small-tile
