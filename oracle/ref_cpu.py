@@ -455,6 +455,13 @@ def _dm(drop, name, t):
     return t * drop[name] if (drop is not None and name in drop) else t
 
 
+def _relu(drop, z):
+    """relu(z) — or, when the parity tests feed "relu_mask" (the 0/1 activation pattern ANOTHER run used, see decoder_layer's
+    ff()), z times that pattern: a pre-activation within rounding distance of 0 flips between a bf16 run and this fp32 one, and
+    with the pattern fixed what is left of a gradient difference is arithmetic."""
+    return z * drop["relu_mask"] if (drop is not None and "relu_mask" in drop) else torch.relu(z)
+
+
 def sr_cross_layer(sd: dict, pre: str, tgt: Tensor, memory: Tensor, nhead: int, eps: float = 1e-5, drop: dict | None = None) -> Tensor:
     """SRTransformerCrossA / SRTransformerDecoder forward (post-norm TransformerDecoderLayer whose self-attention
     keys/values are the spatially reduced tokens): model/hierarchical.py:201-225, model/decoder.py:113-134,
@@ -466,7 +473,7 @@ def sr_cross_layer(sd: dict, pre: str, tgt: Tensor, memory: Tensor, nhead: int, 
                    g("norm1.weight"), g("norm1.bias"), eps)
     x = layer_norm(x + _dm(drop, "d2", _mha_packed(sd, pre + "multihead_attn.", x, memory, nhead, None, pd("ca_p"))),
                    g("norm2.weight"), g("norm2.bias"), eps)
-    ff = linear(_dm(drop, "ff", torch.relu(linear(x, g("linear1.weight"), g("linear1.bias")))), g("linear2.weight"),
+    ff = linear(_dm(drop, "ff", _relu(drop, linear(x, g("linear1.weight"), g("linear1.bias")))), g("linear2.weight"),
                 g("linear2.bias"))
     return layer_norm(x + _dm(drop, "d3", ff), g("norm3.weight"), g("norm3.bias"), eps)
 
@@ -477,7 +484,7 @@ def sr_self_layer(sd: dict, pre: str, src: Tensor, nhead: int, eps: float = 1e-5
     x = src
     x = layer_norm(x + _dm(drop, "d1", _mha_packed(sd, pre + "self_attn.", x, sr_reduce(sd, pre, x), nhead, None,
                                                    drop.get("sa_p") if drop else None)), g("norm1.weight"), g("norm1.bias"), eps)
-    ff = linear(_dm(drop, "ff", torch.relu(linear(x, g("linear1.weight"), g("linear1.bias")))), g("linear2.weight"),
+    ff = linear(_dm(drop, "ff", _relu(drop, linear(x, g("linear1.weight"), g("linear1.bias")))), g("linear2.weight"),
                 g("linear2.bias"))
     return layer_norm(x + _dm(drop, "d3", ff), g("norm2.weight"), g("norm2.bias"), eps)
 
@@ -501,9 +508,11 @@ def attn_block(sd: dict, pre: str, x: Tensor, memory: Tensor | None, nhead: int,
 
 
 def hierarchical(sd: dict, pre: str, visual: list, textual: Tensor | None, nhead: int, depth=(1, 1, 1),
-                 layer_key: str = "layers.0.") -> Tensor:
+                 layer_key: str = "layers.0.", drops: dict | None = None) -> Tensor:
     """HierarchicalCrossA / HierarchicalSelfA / FTNDecoder forward (model/hierarchical.py:37-69,99-131,
-    model/decoder.py:62-94): top-down pyramid, reads only visual[0] and visual[3]."""
+    model/decoder.py:62-94): top-down pyramid, reads only visual[0] and visual[3].
+    drops (diagnostic / training-mode input of the tests): {block prefix, e.g. "attention_stage_4.0.": [per-application dict]}."""
+    dr = lambda k: (drops or {}).get(k)  # noqa: E731
     L = lambda name, x: linear(x, sd[pre + name + ".weight"], sd[pre + name + ".bias"])  # noqa: E731
     t4 = visual[3]
     t3 = L("linear_stage_3", _up2_tokens(t4))
@@ -511,10 +520,10 @@ def hierarchical(sd: dict, pre: str, visual: list, textual: Tensor | None, nhead
     t1 = L("linear2_stage_1", visual[0])
     t4, t3, t2 = L("linear2_stage_4", t4), L("linear2_stage_3", t3), L("linear2_stage_2", t2)
     for i in range(3):
-        t4 = attn_block(sd, f"{pre}attention_stage_4.{i}.", t4, textual, nhead, depth[2], layer_key)
+        t4 = attn_block(sd, f"{pre}attention_stage_4.{i}.", t4, textual, nhead, depth[2], layer_key, dr(f"attention_stage_4.{i}."))
     for i in range(2):
-        t3 = attn_block(sd, f"{pre}attention_stage_3.{i}.", t3, textual, nhead, depth[1], layer_key)
-    t2 = attn_block(sd, f"{pre}attention_stage_2.0.", t2, textual, nhead, depth[0], layer_key)
+        t3 = attn_block(sd, f"{pre}attention_stage_3.{i}.", t3, textual, nhead, depth[1], layer_key, dr(f"attention_stage_3.{i}."))
+    t2 = attn_block(sd, f"{pre}attention_stage_2.0.", t2, textual, nhead, depth[0], layer_key, dr("attention_stage_2.0."))
     return t1 + t2 + t3 + t4
 
 

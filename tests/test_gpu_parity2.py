@@ -220,9 +220,12 @@ def test_config2_full_depth_vs_oracle(dev):
     # measured: logits rel-L2 6.4e-3, max-abs 6.0e-3 of the largest logit, argmax agreement 99.05 % (random-init logits are
     # nearly tied), CE 16.9624 vs 16.9638, gradients 0.7-1.9e-2
     assert r < 1.3e-2 and mx < 1.2e-2, (r, mx)
-    assert agree > 0.98, agree
+    # argmax agreement: measured 0.9905, bound = 1 - 2 x (1 - measured).  BASELINE.md §4's 99.9 % starting gate is for TRAINED
+    # weights (separated classes); at random init the top-2 logit margin of ~1 % of the pixels is below the 6e-3 logit error, and
+    # what the gate protects — identical mIoU — is asserted on a fitted model in test_miou_gate_* below.
+    assert agree > 0.981, agree
     assert abs(loss.item() - float(ref_loss)) < 5e-3
-    assert worst < 4e-2, worst
+    assert worst < 4e-2, worst   # measured 1.9e-2 (x 2)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -10,7 +10,7 @@
   with the gradient list of test_config2_full_depth_vs_oracle;
 * the mIoU edge case of metrics.py:94-97 (an image whose label holds only ignore_index gives NaN, like the reference).
 
-Measured values land in gpurun_out/parity_r03.json (copied to profiles/r03_parity.json).
+Measured values land in gpurun_out/parity_r04.json (copied to profiles/r04_parity.json; round 3's: profiles/r03_parity.json).
 """
 import json
 import math
@@ -38,7 +38,7 @@ def _note(k, v):
     out = Path(os.environ.get("GRAFT_REPO_ROOT", ".")) / "gpurun_out"
     try:
         out.mkdir(exist_ok=True)
-        (out / "parity_r03.json").write_text(json.dumps(REPORT, indent=1))
+        (out / "parity_r04.json").write_text(json.dumps(REPORT, indent=1))
     except OSError:
         pass
 
@@ -176,20 +176,41 @@ def test_config5_real_shapes_vs_oracle(dev):
     textual = torch.randn(1, K, dim, generator=g)
     labels = torch.randint(0, K, (1, 512, 512), generator=g)
     labels[:, :40] = -100                                            # a band of ignored pixels (nn.CrossEntropyLoss default)
-    # oracle (fp32, the box's host cores)
-    params = {k: v.clone().requires_grad_(True) for k, v in w.items()}
-    vis_r = [v.clone().requires_grad_(True) for v in visual]
-    txt_r = textual.clone().requires_grad_(True)
-    emb_r = O.hierarchical(params, "", vis_r, txt_r, nhead=8, depth=(1, 1, 1), layer_key="layers.0.")
-    sm_r = O.score_map_tail(emb_r, txt_r, 4)
-    loss_r = O.cross_entropy(sm_r, labels)
-    loss_r.backward()
-    # HIP
+    def oracle(drops):   # fp32, the box's host cores
+        params = {k: v.clone().requires_grad_(True) for k, v in w.items()}
+        vis_r = [v.clone().requires_grad_(True) for v in visual]
+        txt_r = textual.clone().requires_grad_(True)
+        emb_r = O.hierarchical(params, "", vis_r, txt_r, nhead=8, depth=(1, 1, 1), layer_key="layers.0.", drops=drops)
+        sm_r = O.score_map_tail(emb_r, txt_r, 4)
+        loss_r = O.cross_entropy(sm_r, labels)
+        loss_r.backward()
+        return params, vis_r, txt_r, emb_r, sm_r, loss_r
+
+    params, vis_r, txt_r, emb_r, sm_r, loss_r = oracle(None)
+    # HIP (recording the relu output every SR layer saved for its backward: its sign is the activation pattern the HIP path used)
+    import lc2is_amd.nn.hier as Hm
     m = m.to(dev).train()
     vis = [v.to(dev).requires_grad_(True) for v in visual]
     txt = textual.to(dev).requires_grad_(True)
-    emb = m(vis, txt)
+    acts, orig_fwd = [], Hm._sr_layer_fwd
+
+    def recording(x32, x16, mem16, layer, s_, B_, P_, K_, save, ds=None):
+        y32, y16, sv = orig_fwd(x32, x16, mem16, layer, s_, B_, P_, K_, save, ds)
+        if sv is not None:
+            acts.append((P_, sv["a"]))
+        return y32, y16, sv
+
+    Hm._sr_layer_fwd = recording
+    try:
+        emb = m(vis, txt)
+    finally:
+        Hm._sr_layer_fwd = orig_fwd
     assert emb.shape == (1, 16384, dim)
+    # six SR layer applications, in the pyramid's order: stage 4 at 256 / 1024 / 4096 tokens, stage 3 at 1024 / 4096, stage 2 at 4096
+    assert [p_ for p_, _ in acts] == [256, 1024, 4096, 1024, 4096, 4096]
+    keys = ["attention_stage_4.0.", "attention_stage_4.1.", "attention_stage_4.2.", "attention_stage_3.0.", "attention_stage_3.1.",
+            "attention_stage_2.0."]
+    fed_drops = {k: [{"relu_mask": (a > 0).float().cpu().view(1, p_, -1)}] for k, (p_, a) in zip(keys, acts)}
     r_emb = _rel(emb, emb_r.detach())
     _note("config5_real/embeddings_rel", r_emb)
     with torch.no_grad():
@@ -205,24 +226,44 @@ def test_config5_real_shapes_vs_oracle(dev):
     rv0, rv3, rt = _rel(vis[0].grad, vis_r[0].grad), _rel(vis[3].grad, vis_r[3].grad), _rel(txt.grad, txt_r.grad)
     _note("config5_real/dvisual0", rv0); _note("config5_real/dvisual3", rv3); _note("config5_real/dtextual", rt)
     assert vis[1].grad is None and vis[2].grad is None                # never read (model/hierarchical.py:102-112)
-    worst, worst_k = 0.0, None
+    # the same gradients against the oracle FED the HIP path's six relu patterns (the relu-flip
+    # explanation of a7 / config 2 shown for the three-stage post-norm SR stack itself)
+    params_f, vis_f, txt_f, emb_f, _, loss_f = oracle(fed_drops)
+    fv0, fv3, ft = _rel(vis[0].grad, vis_f[0].grad), _rel(vis[3].grad, vis_f[3].grad), _rel(txt.grad, txt_f.grad)
+    _note("config5_real/fed/dvisual0", fv0); _note("config5_real/fed/dvisual3", fv3); _note("config5_real/fed/dtextual", ft)
+    _note("config5_real/fed/embeddings_rel", _rel(emb, emb_f.detach())); _note("config5_real/fed/loss_oracle", loss_f.item())
+    worst, worst_k, worst_f, worst_fk = 0.0, None, 0.0, None
     for k in ("linear2_stage_1.weight", "linear2_stage_4.weight", "linear_stage_3.weight",
               "attention_stage_4.2.layers.0.self_attn.in_proj_weight", "attention_stage_4.2.layers.0.sr.weight",
               "attention_stage_3.1.layers.0.multihead_attn.out_proj.weight", "attention_stage_2.0.layers.0.linear1.weight",
               "attention_stage_4.0.layers.0.norm.weight"):
         if k not in named:
             continue
-        rg = _rel(named[k].grad, params[k].grad)
-        _note("config5_real/grad/" + k, rg)
+        rg, rf = _rel(named[k].grad, params[k].grad), _rel(named[k].grad, params_f[k].grad)
+        _note("config5_real/grad/" + k, rg); _note("config5_real/fed/grad/" + k, rf)
         if rg > worst:
             worst, worst_k = rg, k
+        if rf > worst_f:
+            worst_f, worst_fk = rf, k
     _note("config5_real/params_checked", sum(1 for k in REPORT if k.startswith("config5_real/grad/")))
-    assert r_emb < 1.5e-2, r_emb
-    assert sm_err < 1e-2 and agree > 0.97, (sm_err, agree)            # cosine scores in [-1, 1]
+    # Thresholds = measured value x <= 2 (profiles/r04_parity.json; round 3 allowed 2.3-3x).  Own-mask oracle: embeddings 3.8e-3,
+    # score map 9.6e-4, argmax agreement 0.9929 (cosine scores of near-tied classes under random weights: the 0.7 % that differ have
+    # top-2 margins below the 1e-3 score error — BASELINE.md's 99.9 % gate is for trained weights and is covered by the mIoU gates
+    # of test_gpu_parity2.py), dvisual0 3.3e-3, dvisual3 2.6e-2, dtextual 6.5e-3, worst parameter gradient 3.5e-2.
+    assert r_emb < 7.5e-3, r_emb
+    assert sm_err < 2e-3 and agree > 0.986, (sm_err, agree)           # cosine scores in [-1, 1]
     assert abs(loss.item() - loss_r.item()) < 3e-3
-    assert rv0 < 3e-2 and rv3 < 8e-2 and rt < 8e-2, (rv0, rv3, rt)
+    assert rv0 < 7e-3 and rv3 < 5.2e-2 and rt < 1.3e-2, (rv0, rv3, rt)
     assert sum(1 for k in REPORT if k.startswith("config5_real/grad/")) >= 4
-    assert worst < 8e-2, (worst_k, worst)
+    assert worst < 7e-2, (worst_k, worst)
+    # fed-mask oracle: what is left is bf16 arithmetic through three post-norm stages (measured values in profiles/r04_parity.json)
+    assert fv3 < FED_DV3_MAX and worst_f < FED_GRAD_MAX, (fv3, worst_fk, worst_f)
+    assert fv3 < rv3 and worst_f < worst, ("the activation pattern should explain part of the error", fv3, rv3, worst_f, worst)
+
+
+# measured with the fed masks (round 4): dvisual3 2.6e-2 -> 5.1e-3, worst parameter gradient 3.5e-2 -> 7.5e-3 (attention_stage_4.0's
+# shared norm), dtextual 6.5e-3 -> 4.8e-3: the relu pattern carried 4/5 of the config-5 gradient error.  Bounds = measured x 2.
+FED_DV3_MAX, FED_GRAD_MAX = 1.0e-2, 1.5e-2
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -275,6 +316,47 @@ def test_config4_depth4_gradients_vs_oracle(dev):
     assert r < 1.5e-2, r
     assert abs(loss.item() - float(ref_loss)) < 1e-2
     assert worst < 4e-2, (worst_k, worst)
+
+
+def test_config4_full_depth_forward_and_loss_vs_oracle(dev):
+    """BASELINE configs[3] at its REAL depth: ViT-L/14 @640x640 (2026 tokens, width 1024, 16 heads, ff 4096), all 24 layers; CLIP
+    text width 768 / 12 heads, 12 layers; decoder d_model 1024 / 8 heads (head_dim 128) / d_kv 768; output 180x180, B = 1.
+    Forward logits and the CE loss against the fp32 CPU oracle (no gradient list: test_config4_depth4_gradients_vs_oracle
+    carries those; the oracle's 24-layer forward is a few seconds on the box's cores).  Tolerances: measured x 2
+    (profiles/r04_parity.json)."""
+    import lc2is_amd.nn as N
+    from oracle import ref_cpu as O
+    torch.manual_seed(24)
+    m = N.BaseModelWithText(14, 640, 180, vision_arch=N.ClipArch(1024, 16, 24, 4096),
+                            text_arch=N.ClipArch(768, 12, 12, 3072, vocab=1000, eos_token_id=999), nhead=8)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(25)
+    B, L = 1, 8
+    inputs = dict(pixel_values=torch.randn(B, 3, 640, 640, generator=g), input_ids=torch.randint(1, 998, (B, L), generator=g),
+                  attention_mask=torch.ones(B, L, dtype=torch.int64))
+    inputs["input_ids"][:, -1] = 999
+    labels = torch.randint(0, 151, (B, 180, 180), generator=g)
+    cfg = O.BaseCfg(in_size=640, out_size=180, patch=14, vision=O.ClipCfg(1024, 16, 24, patch=14),
+                    text=O.ClipCfg(768, 12, 12, eos_token_id=999), dec_heads=8, dec_layers=1)
+    with torch.no_grad():
+        _, _, ref_logits = O.base_model_with_text(sd, inputs, cfg)
+        ref_loss = O.cross_entropy(ref_logits, labels, -100)
+    m = m.to(dev).eval()
+    dinputs = {k: v.to(dev) for k, v in inputs.items()}
+    with torch.no_grad():
+        out = m(dinputs)["outputs"]
+        loss = m.forward_loss(dinputs, labels.to(dev))
+    r = _rel(out, ref_logits)
+    agree = (out.argmax(1).cpu() == ref_logits.argmax(1)).float().mean().item()
+    _note("config4_d24/logits_rel", r); _note("config4_d24/argmax_agreement", agree)
+    _note("config4_d24/loss_hip", loss.item()); _note("config4_d24/loss_oracle", float(ref_loss))
+    assert out.shape == (B, 151, 180, 180)
+    assert r < CFG4_D24_LOGITS_MAX, r
+    assert abs(loss.item() - float(ref_loss)) < CFG4_D24_LOSS_MAX
+
+
+# measured (round 4): logits rel-L2 6.6e-3, argmax agreement 0.9915 (random weights), loss 17.1838 vs 17.1778.  Bounds = measured x 2.
+CFG4_D24_LOGITS_MAX, CFG4_D24_LOSS_MAX = 1.3e-2, 1.2e-2
 
 
 # ---------------------------------------------------------------------------------------------------------------------
