@@ -102,9 +102,14 @@ int lc2is_gemm_tn_grouped(const lc2is_tn_problem* problems, int n, void* workspa
                           lc2is_stream_t stream);
 /* A lc2is_gemm_tn_grouped call of more than 128 problems made under stream capture uploads its descriptor table through a
    memcpy node that re-reads a pinned host image at every replay; the image belongs to the graph that captured it.  This frees
-   every such image (returns how many): call it once the graphs captured so far have been destroyed (lc2is_amd.step.TrainStep
-   does, when a captured step is released or re-captured).  No reference counterpart (host-side resource management). */
+   every such image (returns how many): call it once ALL graphs captured so far have been destroyed.  Per-graph ownership:
+   lc2is_captured_tables_mark() before and after a capture brackets the images that capture registered, and
+   lc2is_release_captured_tables_range(first, last) frees exactly those once that graph is destroyed (lc2is_amd.step.TrainStep
+   does, when a captured step is released or captured again) — other live graphs keep theirs.  No reference counterpart
+   (host-side resource management). */
 int lc2is_release_captured_tables(void);
+int lc2is_captured_tables_mark(void);
+int lc2is_release_captured_tables_range(int first, int last);
 
 /* db[N] (fp32) = column sums of dY[M,N] (bias gradient). workspace >= lc2is_colsum_workspace_bytes. */
 size_t lc2is_colsum_workspace_bytes(int M, int N);

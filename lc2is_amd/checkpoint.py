@@ -30,27 +30,62 @@ def _read_state(path: Path) -> dict:
     return sd.get("state_dict", sd) if all(isinstance(k, str) for k in sd) else sd
 
 
+def _dist():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist, dist.get_rank(), dist.get_world_size()
+    return None, 0, 1
+
+
 def save_checkpoint(model: nn.Module, out_dir: str | Path, train_step: int) -> Path:
-    """engine.py:186-190 — ``<out_dir>/checkpoints/step-<N>.pt`` holding ``model.state_dict()``."""
+    """engine.py:186-190 — ``<out_dir>/checkpoints/step-<N>.pt`` holding ``model.state_dict()``.
+
+    Under data parallelism EVERY rank calls this (it contains a collective): the replicas hold the same parameters, so rank 0
+    alone writes the files; the dropout stream, however, differs per rank (``DropoutRng`` derives it from the torch seed AND
+    the rank), so the states of all ranks are gathered and the sidecar carries one entry per rank."""
+    dist, rank, world = _dist()
     d = Path(out_dir) / "checkpoints"
-    d.mkdir(parents=True, exist_ok=True)
     f = d / f"step-{train_step}.pt"
-    torch.save({k: v.detach().cpu() for k, v in model.state_dict().items()}, f)
     # the dropout stream is not part of the reference's file (it would break the interchange): a JSON sidecar carries it, so a
-    # resumed run draws the masks the uninterrupted run would have drawn
+    # resumed run draws the masks the uninterrupted run would have drawn — on every rank
     from .nn.base import DropoutRng
-    if DropoutRng.get_state() is not None:
-        (d / f"step-{train_step}.rng.json").write_text(json.dumps({"dropout_rng_state": DropoutRng.get_state()}))
+    states = [DropoutRng.get_state()]
+    if dist is not None and world > 1:
+        states = [None] * world
+        dist.all_gather_object(states, DropoutRng.get_state())
+    if rank == 0:
+        d.mkdir(parents=True, exist_ok=True)
+        torch.save({k: v.detach().cpu() for k, v in model.state_dict().items()}, f)
+        side = d / f"step-{train_step}.rng.json"
+        if any(st is not None for st in states):
+            side.write_text(json.dumps({"train_step": int(train_step), "world_size": world,
+                                        "dropout_rng_state": {str(r): st for r, st in enumerate(states)}}))
+        elif side.exists():
+            side.unlink()                      # never leave a stale stream beside a fresh step-N.pt
+    if dist is not None and world > 1:
+        dist.barrier()                         # the files exist when any rank returns
     return f
 
 
 def load_checkpoint(model: nn.Module, path: str | Path, strict: bool = True):
-    """Load a reference ``step-N.pt`` (or one written by :func:`save_checkpoint`) into a drop-in model."""
-    result = model.load_state_dict(_read_state(Path(path)), strict=strict)
-    side = Path(path).with_suffix(".rng.json")
+    """Load a reference ``step-N.pt`` (or one written by :func:`save_checkpoint`) into a drop-in model.  A dropout-stream
+    sidecar is adopted only when it names the same train step as the file and holds an entry for this rank at this world
+    size (a sidecar left behind by another run beside a reference ``step-N.pt`` is ignored: the stream then stays the one
+    derived from the torch seed and the rank)."""
+    path = Path(path)
+    result = model.load_state_dict(_read_state(path), strict=strict)
+    side = path.with_suffix(".rng.json")
     if side.is_file():
         from .nn.base import DropoutRng
-        DropoutRng.set_state(json.loads(side.read_text())["dropout_rng_state"])
+        _, rank, world = _dist()
+        try:
+            meta = json.loads(side.read_text())
+            st = meta["dropout_rng_state"]
+            step_ok = path.stem == f"step-{meta['train_step']}"
+        except (ValueError, KeyError, TypeError):
+            st, step_ok = None, False
+        if isinstance(st, dict) and step_ok and int(meta.get("world_size", -1)) == world and str(rank) in st:
+            DropoutRng.set_state(st[str(rank)])
     for m in model.modules():                      # bf16 weight shadows are rebuilt on the next forward
         if hasattr(m, "invalidate_shadows"):
             m.invalidate_shadows()

@@ -591,12 +591,12 @@ int launch_attn_bwd(const AttnBwdArgs& a, hipStream_t stream) {
   using Cfg = AttnCfg<D>;
   constexpr int OBUF = 4 * 32 * (2 * D + 16);
   constexpr int LDS_DQ2 = Cfg::NSTAGE * Cfg::STAGE > OBUF ? Cfg::NSTAGE * Cfg::STAGE : OBUF;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DevOnce attr_set;
+  if (attr_set.need()) {
     if (hipFuncSetAttribute((const void*)k1b, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ2) != hipSuccess ||
         hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_KV) != hipSuccess)
       return LC2IS_ERR_LAUNCH;
-    attr_set = true;
+    attr_set.done();
   }
   hipLaunchKernelGGL(k1b, dim3(((a.Sq + 127) / 128) * a.H * a.B), dim3(256), LDS_DQ2, stream, a);
   int rc = lc2is_check_launch();

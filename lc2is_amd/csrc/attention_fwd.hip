@@ -353,11 +353,11 @@ int launch_attn_fwd(const AttnFwdArgs& a, hipStream_t stream) {
   auto kern = attn_fwd_kernel<D, DROP>;
   constexpr int OBUF = 4 * 32 * (2 * D + 16);
   constexpr int LDS = Cfg::NSTAGE * Cfg::STAGE > OBUF ? Cfg::NSTAGE * Cfg::STAGE : OBUF;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DevOnce attr_set;
+  if (attr_set.need()) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
       return LC2IS_ERR_LAUNCH;
-    attr_set = true;
+    attr_set.done();
   }
   hipLaunchKernelGGL(kern, dim3(((a.Sq + 127) / 128) * a.H * a.B), dim3(256), LDS, stream, a);
   return lc2is_check_launch();

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 typedef unsigned short bf16_t;  // raw bf16 bits in HBM
 
@@ -194,6 +195,19 @@ __global__ __launch_bounds__(1024) void partials_reduce_kernel(const float* __re
   partials_reduce_body(ws + blockIdx.y * ws_off_y, nparts, stride, W, out, accumulate, blockIdx.x);
 }
 }  // namespace
+
+// "done once PER DEVICE": hipFuncSetAttribute(MaxDynamicSharedMemorySize) belongs to a function ON a device, so a process that
+// drives a second GPU must set it there too (a per-process flag let such a launch fail with ~78 KB of dynamic LDS requested)
+static inline int lc2is_cur_dev() {
+  int d = 0;
+  (void)hipGetDevice(&d);
+  return d & 63;
+}
+struct DevOnce {
+  std::atomic<unsigned long long> mask{0};
+  bool need() const { return !((mask.load(std::memory_order_acquire) >> lc2is_cur_dev()) & 1ull); }
+  void done() { mask.fetch_or(1ull << lc2is_cur_dev(), std::memory_order_release); }
+};
 
 static inline int lc2is_check_launch() {
   hipError_t e = hipGetLastError();

@@ -872,11 +872,11 @@ int launch_cfg(const GemmNtArgs& a, hipStream_t stream, int batch = 1) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int LDS = 2 * (BM + BN) * 128;
   auto kern = gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N>;
-  static bool attr_set = false;  // idempotent; a race only repeats the same call
-  if (!attr_set) {
+  static DevOnce attr_set;  // idempotent; a race only repeats the same call
+  if (attr_set.need()) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
       return LC2IS_ERR_LAUNCH;
-    attr_set = true;
+    attr_set.done();
   }
   const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
   hipLaunchKernelGGL(kern, dim3(ntm * ntn, batch), dim3(NT), LDS, stream, a);
@@ -889,11 +889,11 @@ int launch_dma(const GemmNtArgs& a, hipStream_t stream) {
   constexpr int STAGES = 2 * (BM + BN) * 128, PATCHES = EPI == -2 ? WAVES_M * WAVES_N * 64 * 272 : 0;   // fp32 epilogue patches overlay the stages
   constexpr int LDS = STAGES > PATCHES ? STAGES : PATCHES;
   auto kern = gemm_nt_dma_kernel<BM, BN, WAVES_M, WAVES_N, EPI>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DevOnce attr_set;
+  if (attr_set.need()) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
       return LC2IS_ERR_LAUNCH;
-    attr_set = true;
+    attr_set.done();
   }
   const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
   hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(NT), LDS, stream, a);
@@ -903,12 +903,12 @@ int launch_dma(const GemmNtArgs& a, hipStream_t stream) {
 template <int ACT>
 int launch_persist2_act(const GemmNtArgs& a, hipStream_t stream) {
   constexpr int LDS = (256 + 256) * 128 + 8 * 64 * 144;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DevOnce attr_set;
+  if (attr_set.need()) {
     if (hipFuncSetAttribute((const void*)gemm_nt_persist2_kernel<ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
         hipSuccess)
       return LC2IS_ERR_LAUNCH;
-    attr_set = true;
+    attr_set.done();
   }
   const int ntiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
   const int grid = ntiles < 256 ? ntiles : 256;
@@ -1016,8 +1016,7 @@ extern "C" int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw
   const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
   static const long cfg6_min = getenv("LC2IS_GEMM_CFG6_MIN") ? atol(getenv("LC2IS_GEMM_CFG6_MIN")) : 128;   // (512 and the register-staged 128x128 kernel below it measured 0.8 % slower on config 5)
   if (!(tiles128 >= 1024 && N % 256 == 0)) {
-    if (tiles128 >= 1024 && N % 256 == 0) cfg = 4;
-    else if (tiles128 >= cfg6_min) cfg = 6;              // 128x128 LDS-DMA tiles, 2 blocks/CU
+    if (tiles128 >= cfg6_min) cfg = 6;              // 128x128 LDS-DMA tiles, 2 blocks/CU
     else if (tiles128 >= 128) cfg = 1;
     else cfg = 3;                                        // small problem: 64x64 tiles to fill the chip
     return launch_by_cfg(a, cfg, stream);
@@ -1055,16 +1054,16 @@ extern "C" int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw
   int best_cfg = 0, best_main = M;
   double best_cost = 1e300;
   for (int split = 0; split < 2; ++split)
-    for (int c : {4}) {   // 10 (128x384) measured ~45 % slower per flop than 256x256: kept for experiments only
-      const int bm = c == 4 ? 256 : 128, bn = c == 4 ? 256 : 384;
+    for (int c : {4}) {   // (one candidate tile shape: 128x384 measured ~45 % slower per flop and left the library)
+      const int bm = 256, bn = 256;
       if (N % bn) continue;
       const int r = M % bm;
       if (split && (r == 0 || r > 64 || M <= bm)) continue;
       const int mm = split ? M - r : M;
       const long tiles = (long)((mm + bm - 1) / bm) * (N / bn);
-      double cost = (double)((tiles + 255) / 256) * bm * bn * (c == 10 ? 1.04 : 1.0);   // 4/3 of the L2->LDS traffic
+      double cost = (double)((tiles + 255) / 256) * bm * bn;
       if (split) cost += 65536.0 * 0.3 * 768.0 / K;                                      // ~8 us for the extra launch
-      if (c != 4 || split) cost *= 1.03;                                                 // prefer the plain plan on near-ties
+      if (split) cost *= 1.03;                                                            // prefer the plain plan on near-ties
       if (cost < best_cost) { best_cost = cost; best_cfg = c; best_main = mm; }
     }
   if (best_main == M) return launch_by_cfg(a, best_cfg, stream);

@@ -613,19 +613,19 @@ extern "C" int lc2is_gemm_tn_bf16(const void* dY, int ldy, const void* X, int ld
   const TnPlan p = tn_plan(M, N, K);
   const size_t need = lc2is_gemm_tn_workspace_bytes(M, N, K);
   if (need && (!workspace || workspace_bytes < need)) return LC2IS_ERR_WORKSPACE;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DevOnce attr_set;
+  if (attr_set.need()) {
     if (hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             2 * TN_STAGE) != hipSuccess)
       return LC2IS_ERR_LAUNCH;
-    attr_set = true;
+    attr_set.done();
   }
-  static bool attr_big_set = false;
-  if (p.big && !attr_big_set) {
+  static DevOnce attr_big_set;
+  if (p.big && attr_big_set.need()) {
     if (hipFuncSetAttribute((const void*)gemm_tn_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             2 * TD_STAGE) != hipSuccess)
       return LC2IS_ERR_LAUNCH;
-    attr_big_set = true;
+    attr_big_set.done();
   }
   const int grid = p.ntn * p.ntk * p.splits;
   auto launch = [&](float* o, int ldo, size_t o_stride, float* b, size_t b_stride, int acc_flag) {
@@ -767,9 +767,26 @@ static std::vector<void*> g_captured_tables;   // pinned descriptor-table images
 
 extern "C" int lc2is_release_captured_tables(void) {
   std::lock_guard<std::mutex> lock(g_captured_mu);
-  const int n = (int)g_captured_tables.size();
-  for (void* p : g_captured_tables) (void)hipHostFree(p);
+  int n = 0;
+  for (void* p : g_captured_tables)
+    if (p) { (void)hipHostFree(p); ++n; }
   g_captured_tables.clear();
+  return n;
+}
+
+// Per-graph ownership: the images registered between two marks belong to the graph captured in between.
+extern "C" int lc2is_captured_tables_mark(void) {
+  std::lock_guard<std::mutex> lock(g_captured_mu);
+  return (int)g_captured_tables.size();
+}
+
+extern "C" int lc2is_release_captured_tables_range(int first, int last) {
+  std::lock_guard<std::mutex> lock(g_captured_mu);
+  if (first < 0) first = 0;
+  if (last > (int)g_captured_tables.size()) last = (int)g_captured_tables.size();
+  int n = 0;
+  for (int i = first; i < last; ++i)
+    if (g_captured_tables[i]) { (void)hipHostFree(g_captured_tables[i]); g_captured_tables[i] = nullptr; ++n; }   // (slots keep their index)
   return n;
 }
 
@@ -864,8 +881,8 @@ extern "C" int lc2is_gemm_tn_grouped(const lc2is_tn_problem* problems, int n, vo
     t.blk_end[k] = blk;
     t.red_end[k] = red;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DevOnce attr_set;
+  if (attr_set.need()) {
     if (hipFuncSetAttribute((const void*)gemm_tn_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             2 * TD_STAGE) != hipSuccess ||
         hipFuncSetAttribute((const void*)gemm_tn_grouped_tbl_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -875,7 +892,7 @@ extern "C" int lc2is_gemm_tn_grouped(const lc2is_tn_problem* problems, int n, vo
         hipFuncSetAttribute((const void*)gemm_tn_grouped_small_tbl_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             2 * TN_STAGE) != hipSuccess)
       return LC2IS_ERR_LAUNCH;
-    attr_set = true;
+    attr_set.done();
   }
   if (tbl) {
     if (hipMemcpyAsync(workspace, &t, sizeof(TnGroupTbl), hipMemcpyHostToDevice, stream) != hipSuccess) return LC2IS_ERR_LAUNCH;

@@ -591,15 +591,15 @@ extern "C" int lc2is_head_upsample_ce(const float* scores_lo, int ld, const int6
   HeadArgs a{scores_lo, ld, labels, dscores_lo, scores_hi, loss_sum, B, h, w, H, W, C, S, mode, ignore_index,
              grad_scale};
   const int lds_bytes = 2 * FMAX * FMAX * ld * (int)sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DevOnce attr_set;
+  if (attr_set.need()) {
     const int mx = 2 * FMAX * FMAX * CMAX * (int)sizeof(float);
     if (hipFuncSetAttribute((const void*)head_ce_kernel<LC2IS_INTERP_BICUBIC>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
         hipFuncSetAttribute((const void*)head_ce_kernel<LC2IS_INTERP_BILINEAR>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess)
       return LC2IS_ERR_LAUNCH;
-    attr_set = true;
+    attr_set.done();
   }
   if (S == 4 || S == 8 || S == 16) {
     // channel tiles of 16 the kernel runs (tiles past C are masked): the smallest instantiation that covers C inside the row stride
@@ -610,12 +610,12 @@ extern "C" int lc2is_head_upsample_ce(const float* scores_lo, int ld, const int6
     const int t4 = ((H + S / 2 + HT - 1) / HT) * ((W + S / 2 + HT - 1) / HT);
 #define LC2IS_HEAD_GRP(MODE_, TN_, S_)                                                                                       \
   do {                                                                                                                      \
-    static bool attr = false;                                                                                               \
-    if (!attr) {                                                                                                            \
+    static DevOnce attr;                                                                                               \
+    if (attr.need()) {                                                                                                            \
       if (hipFuncSetAttribute((const void*)head_ce_grp_kernel<MODE_, TN_, S_>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                               2 * 7 * 7 * (CMAX + HEAD_PAD) * (int)sizeof(float) + HT * HT * (int)sizeof(int)) != hipSuccess) \
         return LC2IS_ERR_LAUNCH;                                                                                            \
-      attr = true;                                                                                                          \
+      attr.done();                                                                                                          \
     }                                                                                                                       \
     hipLaunchKernelGGL((head_ce_grp_kernel<MODE_, TN_, S_>), dim3(B * t4), dim3(HEAD_THREADS), lds4, stream, a);            \
   } while (0)

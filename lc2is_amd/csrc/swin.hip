@@ -496,11 +496,11 @@ extern "C" int lc2is_swin_attn_bwd(const void* qkv, int ld, const void* o, int l
   a.C = C; a.scale = scale; a.chunk = (nwin + nchunk - 1) / nchunk;
   const int S_ = ws * ws;
   const int lds_mfma = (3 * 32 + 64) * SWM_P + (64 + 128 + 64) * 4 + (S_ * S_ + 64) * (int)sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DevOnce attr_set;
+  if (attr_set.need()) {
     if (hipFuncSetAttribute((const void*)swin_attn_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
       return LC2IS_ERR_LAUNCH;
-    attr_set = true;
+    attr_set.done();
   }
   const int nchunk_eff = (nwin + a.chunk - 1) / a.chunk;
   hipLaunchKernelGGL(swin_attn_bwd_mfma_kernel, dim3(nchunk_eff * nH), dim3(64), lds_mfma, stream, a);

@@ -108,6 +108,15 @@ class DropoutRng:
         return z
 
 
+def assign_rng_names(root) -> None:
+    """Give every submodule of `root` its dotted path as the prefix of its dropout-site names (``DropoutRng.last`` keys,
+    the active-site count of ``TrainStep.capture``): two decoder blocks of one composition both log ``layers.0.d1`` otherwise
+    and overwrite each other's entries.  Compositions call this at the end of ``__init__``; an outer composition overwrites
+    the names an inner one assigned (full paths win).  The seeds themselves do not depend on the names."""
+    for name, mod in root.named_modules():
+        mod.rng_name = (name + ".") if name else ""
+
+
 class DropSites:
     """The dropout sites of ONE layer in ONE training forward: rate + the seed drawn for each site (kept with the saved
     activations, so the backward regenerates the same decisions).  ``None`` stands for "dropout inactive" (eval / p == 0)."""

@@ -20,7 +20,7 @@ from __future__ import annotations
 import torch
 from torch import nn
 
-from .base import require_cuda
+from .base import assign_rng_names, require_cuda
 from .clip import ClipArch, ImageEncoderCLIPFull, TextEncoderCLIPPooler
 from .decoder import DecoderBlock, DecoderLayer, PromptDecoder, PromptLayer
 from .hier import FTNDecoder
@@ -48,6 +48,7 @@ class PromptFTN(nn.Module):
                                             num_layers=prompt_layers)
         self.decoder = FTNDecoder(in_dims=widths, dim=dim, dropout=dropout)
         self.tail = ScoreMapTail(4)
+        assign_rng_names(self)   # prompt_decoder.* and decoder.attention_stage_*.* log their dropout sites under distinct names
 
     def _embeddings(self, inputs: dict):
         B = inputs["pixel_values"].shape[0]
@@ -112,6 +113,7 @@ class DenseClip(nn.Module):
                                                         dropout=prompt_dropout, batch_first=True), num_layers=num_layers)
         self.vision_decoder = DecoderBlock(decoder_layer=DecoderLayer(d_model=hv, d_kv=dim, nhead=nhead, dim_feedforward=dim_feedforward,
                                                                       batch_first=True, norm_first=True), num_layers=num_layers)
+        assign_rng_names(self)   # prompt_decoder.layers.i.* / vision_decoder.layers.i.*: distinct dropout-site names
 
     def forward(self, inputs: dict):
         B = inputs["pixel_values"].shape[0]

@@ -25,7 +25,7 @@ import torch
 from torch import nn
 
 from .. import ops
-from .base import (DropSites, HipModule, WgradBatch, drop_branch_add, drop_branch_grad16, grad_buf, linear_bwd_params,
+from .base import (DropSites, HipModule, assign_rng_names, WgradBatch, drop_branch_add, drop_branch_grad16, grad_buf, linear_bwd_params,
                    require_cuda, vec_grad)
 from .hier import _PackedAttnParams, _packed_param_grads, _split_bias
 
@@ -330,6 +330,7 @@ class Decoder(HipModule):
             Transformer(repeat=3, upsample=True, sr_ratio=2, dim=512, nhead=8, dropout=dropout),
         ])
         self.linears2 = nn.ModuleList([nn.Linear(dim_out[i], 512) for i in range(4)])
+        assign_rng_names(self)   # attentions.i.trans.r.* instead of four times trans.r.*
 
     def _params_for_version(self):
         return [m.weight for m in self.linears] + [m.weight for m in self.linears2]

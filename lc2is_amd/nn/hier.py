@@ -25,7 +25,7 @@ import torch
 from torch import nn
 
 from .. import ops
-from .base import (DropSites, HipModule, WgradBatch, drop_branch_add, drop_branch_grad16, grad_buf, linear_bwd_params,
+from .base import (DropSites, HipModule, assign_rng_names, WgradBatch, drop_branch_add, drop_branch_grad16, grad_buf, linear_bwd_params,
                    require_cuda, vec_grad)
 
 
@@ -571,6 +571,7 @@ class HierarchicalCrossA(_Pyramid):
         self.attention_stage_2 = nn.ModuleList([mk(depth[0]) for _ in range(1)])
         self.attention_stage_3 = nn.ModuleList([mk(depth[1]) for _ in range(2)])
         self.attention_stage_4 = nn.ModuleList([mk(depth[2]) for _ in range(3)])
+        assign_rng_names(self)   # the six blocks log their dropout sites as attention_stage_S.i.srK.* instead of six times srK.*
 
     def forward(self, visual, textual: torch.Tensor) -> torch.Tensor:
         return self._run(visual, textual)
@@ -589,6 +590,7 @@ class HierarchicalSelfA(_Pyramid):
         self.attention_stage_2 = nn.ModuleList([mk(depth[0]) for _ in range(1)])
         self.attention_stage_3 = nn.ModuleList([mk(depth[1]) for _ in range(2)])
         self.attention_stage_4 = nn.ModuleList([mk(depth[2]) for _ in range(3)])
+        assign_rng_names(self)   # the six blocks log their dropout sites as attention_stage_S.i.srK.* instead of six times srK.*
 
     def forward(self, visual) -> torch.Tensor:
         return self._run(visual, None)
@@ -605,6 +607,7 @@ class FTNDecoder(_Pyramid):
         self.attention_stage_2 = nn.ModuleList([mk() for _ in range(1)])
         self.attention_stage_3 = nn.ModuleList([mk() for _ in range(2)])
         self.attention_stage_4 = nn.ModuleList([mk() for _ in range(3)])
+        assign_rng_names(self)   # the six blocks log their dropout sites as attention_stage_S.i.srK.* instead of six times srK.*
 
     def forward(self, visual, textual: torch.Tensor):
         return self._run(visual, textual)

@@ -76,6 +76,8 @@ _ARGTYPES = {
     "lc2is_gemm_tn_grouped_workspace_bytes": [_P, _I],
     "lc2is_gemm_tn_grouped": [_P, _I, _P, _Z, _P],
     "lc2is_release_captured_tables": [],
+    "lc2is_captured_tables_mark": [],
+    "lc2is_release_captured_tables_range": [_I, _I],
     "lc2is_rows_gather": [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _P],
     "lc2is_resample_u8": [_P, _I, _I, _I, _P, _I, _I, _P, _P, _I, _P],
     "lc2is_gather2d_u8": [_P, _I, _I, _I, _P, _I, _I, _P, _P, _P],
@@ -268,6 +270,16 @@ def release_captured_tables() -> int:
     f = _fn("lc2is_release_captured_tables")
     f.restype = C.c_int
     return int(f())
+
+
+def captured_tables_mark() -> int:
+    """Number of captured descriptor-table images registered so far (bracket a capture with two marks)."""
+    return int(_fn("lc2is_captured_tables_mark")())
+
+
+def release_captured_tables_range(first: int, last: int) -> int:
+    """Free the images registered between two marks (the ones ONE captured graph owns), after that graph is destroyed."""
+    return int(_fn("lc2is_release_captured_tables_range")(int(first), int(last)))
 
 
 def colsum(dy: torch.Tensor, db: torch.Tensor | None = None, accumulate: bool = False):

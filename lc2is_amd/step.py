@@ -104,10 +104,15 @@ class TrainStep:
         if DropoutRng.last:   # dropout seeds are kernel ARGUMENTS drawn on the host: a replay would repeat one step's masks
             raise RuntimeError("TrainStep.capture: the model has active dropout / drop-path sites "
                                f"({len(DropoutRng.last)}); their per-step seeds cannot be captured — train eagerly or set the rates to 0")
+        prev = getattr(self, "_captured", None)
+        if prev is not None:          # capturing again: the previous captured step of THIS TrainStep is released first
+            prev.release()
         graph = torch.cuda.CUDAGraph()
         t_before = self.t
+        mark0 = ops.captured_tables_mark()
         with torch.cuda.graph(graph, stream=side):
             static_loss = self.step(static_in, static_lb)
+        mark1 = ops.captured_tables_mark()   # the pinned descriptor-table images registered in between belong to this graph
         self.t = t_before   # capture records the step; nothing ran
 
         def replay(new_inputs: dict, new_labels: torch.Tensor) -> torch.Tensor:
@@ -120,12 +125,20 @@ class TrainStep:
             self.t += 1
             return static_loss
 
+        state = {"live": True}
+
         def release() -> None:
-            """Destroy the captured graph and the pinned descriptor tables its grouped launches own (the only captured step
-            alive: the tables are process-wide).  The replay function must not be called afterwards."""
+            """Destroy the captured graph and the pinned descriptor tables ITS grouped launches own (other captured steps of the
+            process keep theirs).  The replay function must not be called afterwards; releasing twice is a no-op."""
+            if not state["live"]:
+                return
+            state["live"] = False
             torch.cuda.synchronize()
             graph.reset()
-            ops.release_captured_tables()
+            ops.release_captured_tables_range(mark0, mark1)
+            if getattr(self, "_captured", None) is replay:
+                self._captured = None
 
         replay.static_inputs, replay.static_labels, replay.graph, replay.release = static_in, static_lb, graph, release
+        self._captured = replay
         return replay

@@ -1,10 +1,14 @@
 """CPU: checkpoint interchange — Engine.save-style files and local hub-format snapshots load into the
 drop-in modules with the reference's / transformers' key names (host logic only, no kernels)."""
+from pathlib import Path
+
 import torch
 
 import lc2is_amd.nn as N
 from lc2is_amd import checkpoint as C
 from lc2is_amd.nn.clip import ClipArch
+
+ROOT = Path(__file__).resolve().parent.parent
 
 
 def _tiny_arches():
@@ -96,3 +100,66 @@ def test_packed_cross_attention_key_of_equal_width_layers_roundtrips():
     # unequal widths keep the three separate keys
     sd2 = N.PromptDecoder(N.PromptLayer(d_model=128, d_kv=256, nhead=2, dim_feedforward=64, batch_first=True), 1).state_dict()
     assert "layers.0.multihead_attn.k_proj_weight" in sd2 and "layers.0.multihead_attn.in_proj_weight" not in sd2
+
+
+def _rng_worker(rank, world, port, tmp, q):
+    import os
+    import sys
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lc2is_amd import checkpoint as Cc
+    from lc2is_amd.nn.base import DropoutRng
+    torch.manual_seed(11)                                   # the same torch seed everywhere: the rank makes the streams differ
+    first = [DropoutRng.next_seed() for _ in range(2)]
+    m = torch.nn.Linear(4, 4)
+    f = Cc.save_checkpoint(m, tmp, 7)                       # every rank calls (collective); rank 0 writes
+    nxt = [DropoutRng.next_seed() for _ in range(3)]       # what the uninterrupted run draws next on THIS rank
+    DropoutRng.manual_seed(12345)                           # a resumed process starts somewhere else
+    Cc.load_checkpoint(m, f)
+    resumed = [DropoutRng.next_seed() for _ in range(3)]
+    q.put((rank, first, nxt, resumed))
+    dist.destroy_process_group()
+
+
+def test_dropout_rng_sidecar_is_per_rank_under_data_parallelism(tmp_path):
+    """under DP each rank's dropout stream is derived from seed + rank; the sidecar must carry every
+    rank's state (rank 0 writes, after an all_gather_object) so that after a resume rank r continues ITS stream — not rank 0's."""
+    import os
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 777) % 2000
+    procs = [ctx.Process(target=_rng_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = sorted(q.get(timeout=90) for _ in range(2))
+    for p_ in procs:
+        p_.join(timeout=60)
+        assert p_.exitcode == 0
+    (r0, first0, nxt0, res0), (r1, first1, nxt1, res1) = res
+    assert first0 != first1 and nxt0 != nxt1                # the ranks draw different masks
+    assert res0 == nxt0 and res1 == nxt1                    # and each resumes its own stream
+    import json
+    meta = json.loads((tmp_path / "checkpoints" / "step-7.rng.json").read_text())
+    assert meta["train_step"] == 7 and meta["world_size"] == 2 and set(meta["dropout_rng_state"]) == {"0", "1"}
+
+
+def test_stale_dropout_sidecar_is_ignored(tmp_path):
+    """A sidecar that names another train step (left by an earlier run beside a reference step-N.pt) must not be adopted."""
+    import json
+    from lc2is_amd.nn.base import DropoutRng
+    m = torch.nn.Linear(3, 3)
+    torch.manual_seed(3)
+    DropoutRng.next_seed()
+    f = C.save_checkpoint(m, tmp_path, 5)
+    side = f.with_suffix(".rng.json")
+    meta = json.loads(side.read_text())
+    meta["train_step"] = 4
+    side.write_text(json.dumps(meta))
+    DropoutRng.manual_seed(42)
+    before = DropoutRng.get_state()
+    C.load_checkpoint(m, f)
+    assert DropoutRng.get_state() == before

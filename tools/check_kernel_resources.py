@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Register / scratch usage of every kernel in lc2is_amd/csrc (hipcc -Rpass-analysis=kernel-resource-usage, gfx950, no GPU needed).
+Fails when a kernel of the hot path spills (scratch > 0): launch bounds such as head_ce_grp_kernel<*, 12, 4>'s (512, 2) or the
+256-register NT GEMM kernels rely on the allocator staying inside them.  usage: python tools/check_kernel_resources.py [-j N]"""
+import concurrent.futures as cf
+import re
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+CSRC = ROOT / "lc2is_amd" / "csrc"
+HOT = ("gemm_nt_pp_kernel", "gemm_nt_persist2_kernel", "gemm_nt_dma_kernel", "gemm_tn_grouped", "attn_fwd_kernel<64", "attn_fwd_kernel<96",
+       "attn_bwd_dq2_kernel<64", "attn_bwd_dkdv_kernel<64", "attn_bwd_dq2_kernel<96", "attn_bwd_dkdv_kernel<96", "attn_bwd_fused_kernel",
+       "head_ce_grp_kernel", "ln_fwd_kernel", "ln_bwd_kernel", "sgd_kernel")
+# known, accepted (listed so that a NEW spill is a failure): the run-time-switch epilogue instantiation (EPI = -1, activations 5 / 6
+# only — every headline GEMM runs a per-activation instantiation), 12 bytes in the 128-register LayerNorm backward (HBM-bound: 5.4
+# TB/s) and the opt-in fused attention backward
+ACCEPTED = ("gemm_nt_dma_kernel<256, 256, 2, 4, -1>", "gemm_nt_dma_kernel<128, 128, 2, 2, -1>", "ln_bwd_kernel<3>", "attn_bwd_fused_kernel")
+
+
+def demangle(names):
+    out = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.splitlines()
+    return [re.sub(r"\(anonymous namespace\)::", "", o) for o in out]
+
+
+def one(src):
+    cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", f"-I{CSRC}", f"-I{ROOT / 'include'}",
+           "-Wno-unused-function", "-ffp-contract=fast", "-Rpass-analysis=kernel-resource-usage", "--cuda-device-only", "-c", str(src),
+           "-o", "/dev/null"]
+    err = subprocess.run(cmd, capture_output=True, text=True).stderr
+    rows, cur = [], None
+    for line in err.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = dict(name=m.group(1), file=src.name)
+            rows.append(cur)
+            continue
+        for key, pat in (("vgpr", r"VGPRs: (\d+)"), ("agpr", r"AGPRs: (\d+)"), ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"),
+                         ("occ", r"Occupancy \[waves/SIMD\]: (\d+)"), ("vspill", r"VGPRs Spill: (\d+)"), ("lds", r"LDS Size \[bytes/block\]: (\d+)")):
+            m = re.search(pat, line)
+            if m and cur is not None:
+                cur[key] = int(m.group(1))
+    return rows
+
+
+def main():
+    jobs = int(sys.argv[sys.argv.index("-j") + 1]) if "-j" in sys.argv else 4
+    srcs = sorted(CSRC.glob("*.hip"))
+    with cf.ThreadPoolExecutor(jobs) as ex:
+        rows = [r for rs in ex.map(one, srcs) for r in rs]
+    names = demangle([r["name"] for r in rows])
+    bad = []
+    print(f"{'kernel':90s} {'file':24s} {'VGPR':>5s} {'AGPR':>5s} {'occ':>3s} {'scratch':>7s}")
+    for r, n in sorted(zip(rows, names), key=lambda t: (t[0]["file"], t[1])):
+        n = re.sub(r"\(.*", "", n)
+        hot = any(h in n for h in HOT)
+        flag = ""
+        if r.get("scratch", 0) > 0:
+            flag = "  <-- SPILLS" + (" (hot path)" if hot else "")
+            if hot and not any(a in n for a in ACCEPTED):
+                bad.append(n)
+        print(f"{n[:90]:90s} {r['file']:24s} {r.get('vgpr', 0):5d} {r.get('agpr', 0):5d} {r.get('occ', 0):3d} {r.get('scratch', 0):7d}{flag}")
+    if bad:
+        print("\nhot-path kernels with scratch:", *bad, sep="\n  ")
+        sys.exit(1)
+    print("\nno hot-path kernel uses scratch")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The eight NT GEMMs of one ViT-B/16 layer (forward + data gradients) at the headline shape (M = 32 x 1025), each with the
-epilogue the step uses, through the default dispatch (or LC2IS_GEMM_CFG / tile_cfg=<n> as argv[1]); interleaved rounds in one
+epilogue the step uses, through the default dispatch (or tile_cfg=<n>[,<n>...] as argv[1]); interleaved rounds in one
 process, median and min per shape.  Usage: python tools/gemm_shapes.py [tile_cfg] [rounds]"""
 import sys
 from pathlib import Path
