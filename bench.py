@@ -54,7 +54,7 @@ SAMPLE_EVERY = 4   # HIP-event pairs around the dominant kernel on every 4th tim
 
 class GemmTimer:
     """HIP-event timing of every call that runs the dominant kernel — the 256x256 LDS-DMA NT GEMM (gemm_nt_dma_kernel<256,256,2,4>
-    and its persistent form gemm_nt_persist2_kernel, same tile algebra), i.e. the NT GEMMs
+    and its persistent forms gemm_nt_persist2_kernel / gemm_nt_pp_kernel, same tile algebra), i.e. the NT GEMMs
     with >= 1024 128x128 tiles of output and N % 256 == 0 (the dispatch rule of lc2is_gemm_nt_bf16) — recorded on the
     stream the kernel is launched on.  (The small GEMMs of the text tower / decoder use other tile kernels and overlap
     the vision tower on a side stream; they are not part of this kernel's roofline.)"""
@@ -323,7 +323,7 @@ def main():
                        "parallelism": f"dp{world}", "params_M": round(ts.arena.numel / 1e6, 2)},
             "final_loss": loss_val,
             **({"diagnostic": "LC2IS_BENCH_CACHED_TEXT: the text tower is skipped — NOT a benchmark result"} if diag_cached_text else {}),
-            "roofline": {"bound": "mfma", "kernel": "256x256 LDS-DMA NT GEMM: gemm_nt_dma_kernel<256,256,2,4,0,*> + gemm_nt_persist2_kernel<*> (every launch of each 4th timed step)",
+            "roofline": {"bound": "mfma", "kernel": "256x256 LDS-DMA NT GEMM: gemm_nt_dma_kernel<256,256,2,4,*> + its persistent ping-pong form gemm_nt_pp_kernel<*> (every launch of each 4th timed step)",
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": ref.get("dominant_kernel_hbm_bytes_per_launch"),
                          "traffic_source": (f"profiles/roofline_ref.json: {ref.get('dominant_kernel_hbm_source')}"
@@ -331,6 +331,9 @@ def main():
                          # the quantity the north_star target is stated in: whole step (live) and ViT encoder (rocprofv3)
                          "step_frac": (STEP_GF_PER_IMG * 1e9 * (n_img / dt) / world / 1e12 / PEAK_BF16_TFLOPS
                                        if args.patch == 16 and args.in_size == 512 else None),
+                         # rocprof counter evidence for the dominant kernel family (north_star: "rocprof-evidenced MFMA utilisation")
+                         "mfma_busy_frac": ref.get("dominant_kernel_mfma_busy_frac"), "clock_ghz": ref.get("dominant_kernel_clock_ghz"),
+                         "counter_source": ref.get("dominant_kernel_counter_source"),
                          "encoder_frac": ref.get("encoder_frac"),
                          "encoder_kernel_ms_per_step": ref.get("encoder_kernel_ms_per_step"),
                          "bandwidth_kernels": [dict(kernel=b["kernel"], achieved_gbs=round(b["achieved_gbs"], 1), peak_gbs=8000.0,

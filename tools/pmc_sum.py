@@ -1,11 +1,11 @@
 """HBM bytes per launch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over bench.py.
 usage: pmc_sum.py <fetch counter_collection.csv> <write counter_collection.csv> <out prefix> [commit]
 Writes <prefix>_hbm_per_kernel.csv and <prefix>_hbm.json (the dominant kernel: every instantiation of
-gemm_nt_dma_kernel<256, 256, 2, 4, 0, *> and of its persistent form gemm_nt_persist2_kernel<*> aggregated).  Corrections per MI355X_MICROARCH.md (HBM section): FETCH_SIZE is KB
+gemm_nt_dma_kernel<256, 256, 2, 4, 0, *> and of its persistent forms gemm_nt_persist2_kernel<*> / gemm_nt_pp_kernel<*> aggregated).  Corrections per MI355X_MICROARCH.md (HBM section): FETCH_SIZE is KB
 and tallies 128-B requests at 64 B on gfx950 -> bytes = 2 x 1000 x FETCH_SIZE; WRITE_SIZE is KB, exact."""
 import collections, csv, json, re, sys
 
-DOM = ("gemm_nt_dma_kernel<256, 256, 2, 4, 0", "gemm_nt_persist2_kernel<")   # the 256x256 LDS-DMA NT GEMM: plain and persistent forms
+DOM = ("gemm_nt_dma_kernel<256, 256, 2, 4, 0", "gemm_nt_persist2_kernel<", "gemm_nt_pp_kernel<")   # the 256x256 LDS-DMA NT GEMM: plain, persistent and ping-pong forms
 
 
 def per_kernel(path, counter):

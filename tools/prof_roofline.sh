@@ -8,6 +8,7 @@ rocprofv3 --kernel-trace --stats -d $root/gpurun_out/prof_${tag}_full -o p --out
 rocprofv3 --kernel-trace -d $root/gpurun_out/prof_${tag}_enc -o p --output-format csv -- python3 $root/tools/encoder_only.py --steps 3 --warmup 2 > $root/gpurun_out/prof_${tag}_enc.log 2>&1 || { tail -5 $root/gpurun_out/prof_${tag}_enc.log; exit 1; }
 pmc=""
 [ -f $root/gpurun_out/pmc_${tag}_hbm.json ] && pmc="--pmc $root/gpurun_out/pmc_${tag}_hbm.json"
+[ -f $root/gpurun_out/sq_${tag}.json ] && pmc="$pmc --sq $root/gpurun_out/sq_${tag}.json"
 python3 $root/tools/roofline_sum.py $root/gpurun_out/prof_${tag}_full/p_kernel_trace.csv 5 $root/gpurun_out/prof_${tag}_enc/p_kernel_trace.csv 5 $commit $root/gpurun_out/${tag}_roofline.json $pmc
 python3 $root/tools/prof_sum.py $root/gpurun_out/prof_${tag}_full/p_kernel_stats.csv 5 16 > $root/gpurun_out/${tag}_summary.txt
 cp $root/gpurun_out/prof_${tag}_full/p_kernel_stats.csv $root/gpurun_out/${tag}_kernel_stats.csv

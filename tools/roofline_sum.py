@@ -32,6 +32,7 @@ def load(path):
 def main():
     full, nfull, enc, nenc, commit, out_path = sys.argv[1], float(sys.argv[2]), sys.argv[3], float(sys.argv[4]), sys.argv[5], sys.argv[6]
     pmc = sys.argv[sys.argv.index("--pmc") + 1] if "--pmc" in sys.argv else None
+    sq = sys.argv[sys.argv.index("--sq") + 1] if "--sq" in sys.argv else None
     F, E = load(full), load(enc)
     enc_s, rows, short = 0.0, [], []
     for k, durs in E.items():
@@ -82,8 +83,23 @@ def main():
         rec = json.load(open(pmc))
         out["dominant_kernel_hbm_bytes_per_launch"] = rec["hbm_bytes_per_launch"]
         out["dominant_kernel_hbm_source"] = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/prof_pmc.sh) @ {rec.get('commit')}"
+    if sq:   # SQ / GRBM counter evidence (tools/prof_sq.sh): matrix-pipe busy share and effective clock per kernel family
+        rec = json.load(open(sq))
+        out["sq_counters"] = {k: {f: v[f] for f in ("dispatches", "avg_us", "mfma_busy_frac", "clock_ghz", "active", "wait_inst", "wait_any")}
+                              for k, v in rec.items()}
+        dom = {k: v for k, v in rec.items() if k.startswith(("gemm_nt_pp_kernel", "gemm_nt_persist2_kernel", "gemm_nt_dma_kernel<256, 256, 2, 4, 0",
+                                                              "gemm_nt_dma_kernel<256, 256, 2, 4, 1", "gemm_nt_dma_kernel<256, 256, 2, 4, 2",
+                                                              "gemm_nt_dma_kernel<256, 256, 2, 4, 3", "gemm_nt_dma_kernel<256, 256, 2, 4, 4"))}
+        w = sum(v["dispatches"] * v["avg_us"] for v in dom.values())
+        if w:
+            out["dominant_kernel_mfma_busy_frac"] = sum(v["mfma_busy_frac"] * v["dispatches"] * v["avg_us"] for v in dom.values()) / w
+            out["dominant_kernel_clock_ghz"] = sum(v["clock_ghz"] * v["dispatches"] * v["avg_us"] for v in dom.values()) / w
+            out["dominant_kernel_counter_source"] = ("rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE passes over bench.py --steps 2 "
+                                                     f"(tools/prof_sq.sh) @ {commit}; duration-weighted over {sorted(dom)}; the clock reads high on "
+                                                     "dispatches shorter than ~0.3 ms (MI355X_MICROARCH.md, DVFS give-back)")
     json.dump(out, open(out_path, "w"), indent=1)
-    print(json.dumps({k: out[k] for k in ("commit", "kernel_ms_per_step", "encoder_kernel_ms_per_step", "encoder_frac")}))
+    print(json.dumps({k: out.get(k) for k in ("commit", "kernel_ms_per_step", "encoder_kernel_ms_per_step", "encoder_frac",
+                                              "dominant_kernel_mfma_busy_frac", "dominant_kernel_clock_ghz")}))
     for b in out["bandwidth_kernels"]:
         print(f"  {b['kernel']}: {b['avg_us']:.1f} us, {b['achieved_gbs']:.0f} GB/s ({b['frac_of_8tbs']:.2f} of 8 TB/s)")
     if short:
