@@ -478,7 +478,127 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(A
     const float* lsev = (const float*)(cur + 2 * I::TILE);
     const float* delv = lsev + 64;
 
-    if (wave_active) {   // waves past Sk (ragged last block) only help staging
+    const bool h1 = qt * 64 + 32 < p.Sq;   // (a ragged last tile of at most 32 queries has an empty second half: block-uniform)
+    if constexpr (BIAS0 && !DIAG && !DROP) {
+    if (wave_active && h1) {
+      // The vision tower's tiles, software-pipelined AND interleaved (round 4).  A wave issues in order, and an MFMA holds its
+      // issue slot until the matrix pipe takes it (32 cycles back to back), so VALU work only runs beside MFMAs of the SAME wave when
+      // the two alternate in program order (profiles/r04_attn_dkdv_stamps.txt: chains 460, arithmetic 727, products 536 cycles per
+      // half, one after the other).  Here half 1's S / dP chains are issued BETWEEN half 0's exp2 / dS arithmetic (one MFMA, then two score
+      // columns = ~8 VALU instructions, the order pinned by sched_barrier fences; fragments and row stats read ahead of the region),
+      // and half 0's dV^T / dK^T products between half 1's arithmetic.  Measured: dq + dk/dv at B.H = 384, S = 1025: 464 -> 442 us.
+      auto chains = [&](int u, f32x16_t& sa, f32x16_t& dp) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sa[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) {
+          const int a = row_addr[s] + 32 * u * I::PITCH;
+          const bf16x8_t qfr = *(const bf16x8_t*)(cur + a);
+          const bf16x8_t gfr = *(const bf16x8_t*)(cur + I::TILE + a);
+          sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr, kf[s], sa, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gfr, vf[s], dp, 0, 0, 0);
+        }
+      };
+      auto products = [&](int u, const bf16x8_t (&pf)[2], const bf16x8_t (&dsf)[2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s2i = 0; s2i < 2; ++s2i) {
+          const int roff = (32 * u + 16 * s2i) * I::PITCH;
+#pragma unroll
+          for (int d = 0; d < NDT; ++d) {
+            const int lo = tr_lo[d] + roff, hi = tr_hi[d] + roff;
+            const bf16x8_t gtf = tr_frag3(cur + I::TILE, lo, hi);  // dO^T
+            const bf16x8_t qtf = tr_frag3(cur, lo, hi);            // Q^T
+            dvt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gtf, pf[s2i], dvt[d], 0, 0, 0);
+            dkt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, dsf[s2i], dkt[d], 0, 0, 0);
+          }
+        }
+      };
+      f32x16_t sa0, dp0, sa1, dp1;
+      bf16x8_t pf0[2], dsf0[2], pf1[2], dsf1[2];
+      chains(0, sa0, dp0);
+      __builtin_amdgcn_sched_barrier(0);
+      // region: half 1's chains beside half 0's arithmetic, the order pinned chunk by chunk (one or two MFMAs, then two score columns)
+      auto arith2 = [&](int i, f32x16_t& sa, f32x16_t& dp, const f32x4_t& l4, const f32x4_t& d4) __attribute__((always_inline)) {
+        const int c = i >> 1, j = (i & 1) * 2;
+        const f32x2_t sc2 = {p.scale_log2, p.scale_log2};
+        const f32x2_t s2 = f32x2_t{sa[4 * c + j], sa[4 * c + j + 1]} * sc2 - f32x2_t{l4[j], l4[j + 1]};
+        const f32x2_t pr = {__builtin_amdgcn_exp2f(s2[0]), __builtin_amdgcn_exp2f(s2[1])};
+        const f32x2_t ds = pr * (f32x2_t{dp[4 * c + j], dp[4 * c + j + 1]} - f32x2_t{d4[j], d4[j + 1]});
+        sa[4 * c + j] = pr[0];
+        sa[4 * c + j + 1] = pr[1];
+        dp[4 * c + j] = ds[0];
+        dp[4 * c + j + 1] = ds[1];
+      };
+      {
+        bf16x8_t qf1[NKS], gf1[NKS];
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) {
+          const int a = row_addr[s] + 32 * I::PITCH;
+          qf1[s] = *(const bf16x8_t*)(cur + a);
+          gf1[s] = *(const bf16x8_t*)(cur + I::TILE + a);
+        }
+        f32x4_t l4[4], d4[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          l4[c] = *(const f32x4_t*)(lsev + 8 * c + 4 * hh);
+          d4[c] = *(const f32x4_t*)(delv + 8 * c + 4 * hh);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sa1[r] = 0.f; dp1[r] = 0.f; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+          for (int m = i * 2 * NKS / 8; m < (i + 1) * 2 * NKS / 8; ++m) {
+            if (m & 1) dp1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf1[m >> 1], vf[m >> 1], dp1, 0, 0, 0);
+            else       sa1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf1[m >> 1], kf[m >> 1], sa1, 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          arith2(i, sa0, dp0, l4[i >> 1], d4[i >> 1]);
+          if (i & 1) {   // the packed P / dS fragment this column pair completes
+            if ((i >> 1) & 1) { pf0[i >> 2] = pack8(sa0, 8 * (i >> 2)); dsf0[i >> 2] = pack8(dp0, 8 * (i >> 2)); }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      // region: half 0's products beside half 1's arithmetic
+      {
+        bf16x8_t gtf[2 * NDT], qtf[2 * NDT];
+#pragma unroll
+        for (int s2i = 0; s2i < 2; ++s2i) {
+#pragma unroll
+          for (int d = 0; d < NDT; ++d) {
+            const int roff = 16 * s2i * I::PITCH;
+            gtf[s2i * NDT + d] = tr_frag3(cur + I::TILE, tr_lo[d] + roff, tr_hi[d] + roff);
+            qtf[s2i * NDT + d] = tr_frag3(cur, tr_lo[d] + roff, tr_hi[d] + roff);
+          }
+        }
+        f32x4_t l4[4], d4[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          l4[c] = *(const f32x4_t*)(lsev + 32 + 8 * c + 4 * hh);
+          d4[c] = *(const f32x4_t*)(delv + 32 + 8 * c + 4 * hh);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+          for (int m = i * 4 * NDT / 8; m < (i + 1) * 4 * NDT / 8; ++m) {
+            const int f = m >> 1, s2i = f / NDT, d = f % NDT;
+            if (m & 1) dkt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[f], dsf0[s2i], dkt[d], 0, 0, 0);
+            else       dvt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gtf[f], pf0[s2i], dvt[d], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          arith2(i, sa1, dp1, l4[i >> 1], d4[i >> 1]);
+          if ((i & 3) == 3) { pf1[i >> 2] = pack8(sa1, 8 * (i >> 2)); dsf1[i >> 2] = pack8(dp1, 8 * (i >> 2)); }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      products(1, pf1, dsf1);
+    }
+    }
+    const bool pipelined = BIAS0 && !DIAG && !DROP && h1;
+    if (wave_active && !pipelined) {   // waves past Sk (ragged last block) only help staging
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       if (u == 1 && qt * 64 + 32 >= p.Sq) continue;   // a ragged last tile of at most 32 queries: empty second half (block-uniform)
