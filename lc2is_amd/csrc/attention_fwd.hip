@@ -60,12 +60,15 @@ struct AttnFwdArgs {
 // coordinate of a score = (row (b*H + h)*Sq + q, column key), so the backward kernels regenerate the same decisions.
 constexpr float FRAME_THR = 6.0f;
 
-template <int D, bool DROP>
-__global__ __launch_bounds__(256, (D == 64) ? 3 : 2) void attn_fwd_kernel(AttnFwdArgs p) {
+// NQ = 32-query groups per wave.  NQ = 1: 3 waves/SIMD at D = 64.  NQ = 2 (64 queries per wave, 256 per block): every K row
+// fragment and every V^T fragment read from LDS feeds TWO MFMA chains (half the LDS bytes per MFMA, and the S^T chains of the two
+// groups are independent, so they issue back to back instead of waiting out each other's latency) at 2 waves/SIMD.
+template <int D, bool DROP, int NQ>
+__global__ __launch_bounds__(256, NQ == 2 ? (D == 64 ? 2 : 1) : ((D == 64) ? 3 : 2)) void attn_fwd_kernel(AttnFwdArgs p) {
   using Cfg = AttnCfg<D>;
   constexpr int PITCH = Cfg::PITCH, NSTAGE = Cfg::NSTAGE, PD = NSTAGE - 1;
   constexpr int NKS = D / 16, NDT = D / 32;
-  constexpr int QB = 128;               // queries per block (4 waves x 32)
+  constexpr int QB = 128 * NQ;          // queries per block (4 waves x 32 NQ)
   constexpr int OP = 2 * D + 16;        // row pitch of the output staging image (bytes)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -77,8 +80,10 @@ __global__ __launch_bounds__(256, (D == 64) ? 3 : 2) void attn_fwd_kernel(AttnFw
   const int nqb = (p.Sq + QB - 1) / QB;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int bx = tile % nqb, head = (tile / nqb) % p.H, b = tile / (nqb * p.H);
-  const int q0 = bx * QB + wid * 32;                  // first query of this wave
-  const int qrow = q0 + l31;
+  const int q0 = bx * QB + wid * 32 * NQ;             // first query of this wave
+  int qrow[NQ];
+#pragma unroll
+  for (int g = 0; g < NQ; ++g) qrow[g] = q0 + 32 * g + l31;
   const bool wave_active = q0 < p.Sq;                 // wave-uniform; waves wholly past Sq only help staging
   const float NEG_INF = -__builtin_inff();
 
@@ -110,15 +115,17 @@ __global__ __launch_bounds__(256, (D == 64) ? 3 : 2) void attn_fwd_kernel(AttnFw
     if (i < nkt) request(i, i * Cfg::STAGE);
 
   // Q fragments (B operand of S^T = K·Q^T): lane holds Q[qrow][16s + 8hh .. +7]
-  bf16x8_t qf[NKS];
-  {
+  bf16x8_t qf[NQ][NKS];
+  unsigned drop_rh[NQ];
+#pragma unroll
+  for (int g = 0; g < NQ; ++g) {
     const __amdgpu_buffer_rsrc_t rsQ = make_rsrc(p.Q, qbytes);
-    const int off = (qrow < p.Sq) ? ((b * p.Sq + qrow) * p.ldq + head * D + 8 * hh) * 2 : -1;
+    const int off = (qrow[g] < p.Sq) ? ((b * p.Sq + qrow[g]) * p.ldq + head * D + 8 * hh) * 2 : -1;
 #pragma unroll
     for (int s = 0; s < NKS; ++s)
-      qf[s] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rsQ, off < 0 ? -1 : off + s * 32, 0, 0));
+      qf[g][s] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rsQ, off < 0 ? -1 : off + s * 32, 0, 0));
+    drop_rh[g] = DROP ? drop_row_hash(p.drop, (unsigned)((b * p.H + head) * p.Sq + qrow[g])) : 0u;
   }
-  const unsigned drop_rh = DROP ? drop_row_hash(p.drop, (unsigned)((b * p.H + head) * p.Sq + qrow)) : 0u;
 
   // fragment addresses in a stage (the swizzle only looks at row bits 0..3: 16- / 32-row steps are immediates on these bases)
   const int q4 = (lane >> 2) & 3, p4 = lane & 3, cg = (lane >> 4) & 1;
@@ -137,34 +144,43 @@ __global__ __launch_bounds__(256, (D == 64) ? 3 : 2) void attn_fwd_kernel(AttnFw
     asm volatile("" : "+v"(v_lo[d]), "+v"(v_hi[d]));
   }
 
-  f32x16_t ot[NDT];
+  f32x16_t ot[NQ][NDT];
+  f32x2_t lsum2[NQ];               // this lane's share of the row sum (its 16 keys per half tile), even / odd scores apart (packed adds)
+  float m_ref[NQ];                 // the row's frame
+  bool counted[NQ];                // has the row met an unmasked key (its frame is then a real score's maximum)
 #pragma unroll
-  for (int d = 0; d < NDT; ++d)
+  for (int g = 0; g < NQ; ++g) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) ot[d][r] = 0.f;
-  f32x2_t lsum2 = {0.f, 0.f};      // this lane's share of the row sum (its 16 keys per half tile), even / odd scores apart (packed adds)
-  float m_ref = 0.f;               // the row's frame
-  bool counted = false;            // has the row met an unmasked key (its frame is then a real score's maximum)
+    for (int d = 0; d < NDT; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ot[g][d][r] = 0.f;
+    lsum2[g] = f32x2_t{0.f, 0.f};
+    m_ref[g] = 0.f;
+    counted[g] = false;
+  }
 
   // S^T = K · Q^T of one 32-key half tile (raw, unscaled): 4 (D/16) LDS row reads + dependent MFMAs
-  auto issue_s = [&](int so, int t, f32x16_t& st) __attribute__((always_inline)) {
+  auto issue_s = [&](int so, int t, f32x16_t (&st)[NQ]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+    for (int g = 0; g < NQ; ++g)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[g][r] = 0.f;
 #pragma unroll
     for (int s = 0; s < NKS; ++s) {
       const bf16x8_t kf = lds_read_b128(k_row[s] + (unsigned)(so + 32 * t * PITCH));
-      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st, 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < NQ; ++g) st[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[g][s], st[g], 0, 0, 0);
     }
   };
   // block 1 of a half step: scale into the row's frame, masks, per-lane maximum, frame check (the only branch)
   // (masked_c = false_type: the caller knows the tile has no key tail, no causal edge and no key bias — no mask code at all)
-  auto frame = [&](f32x16_t& st, int kt, int t, auto masked_c) __attribute__((always_inline)) {
+  auto frame1 = [&](f32x16_t& st, int g, int kt, int t, auto masked_c) __attribute__((always_inline)) {
     const bool tail = (kt * 64 + 64 > p.Sk);
     const bool diag = p.causal && (kt * 64 + 63 > bx * QB);  // some key may exceed some query
 #pragma unroll
-    for (int r = 0; r < 16; ++r) st[r] = __builtin_fmaf(st[r], p.scale_log2, -m_ref);
+    for (int r = 0; r < 16; ++r) st[r] = __builtin_fmaf(st[r], p.scale_log2, -m_ref[g]);
     if (decltype(masked_c)::value && (tail || diag || p.kbias != nullptr)) {   // key tail / key padding / causal edge: -inf (or the additive key bias) per score
-      int key0 = kt * 64 + 32 * t + 4 * hh, qr = qrow;
+      int key0 = kt * 64 + 32 * t + 4 * hh, qr = qrow[g];
       asm volatile("" : "+v"(key0), "+v"(qr));   // keeps the per-score compares INSIDE this branch (hipcc hoists them otherwise)
 #pragma unroll
       for (int c = 0; c < 4; ++c)
@@ -184,49 +200,59 @@ __global__ __launch_bounds__(256, (D == 64) ? 3 : 2) void attn_fwd_kernel(AttnFw
     ma = max3f(ma, st[10], st[11]);
     mb = max3f(mb, st[12], st[13]);
     const float mx = max2f(max3f(ma, st[14], st[15]), mb);
-    if (__any((mx > FRAME_THR) || (!counted && mx > NEG_INF))) {
+    if (__any((mx > FRAME_THR) || (!counted[g] && mx > NEG_INF))) {
       // rare: some row outgrew its frame (or met its first key): move those rows to the frame of their new maximum
       const float mxx = fmaxf(mx, __shfl_xor(mx, 32, 64));            // the row's maximum over both lane halves
-      const bool move = (mxx > FRAME_THR) || (!counted && mxx > NEG_INF);
+      const bool move = (mxx > FRAME_THR) || (!counted[g] && mxx > NEG_INF);
       const float delta = move ? mxx : 0.f;
       // 1 where nothing moves.  A row's FIRST frame is not a rescale: O and l are exactly 0 and the dummy frame 0 means nothing,
       // so exp2(-delta) must not be formed there (a first maximum below -128 gives +inf, and 0 * inf = NaN in O and l)
-      const float corr = counted ? __builtin_amdgcn_exp2f(-delta) : 1.f;
+      const float corr = counted[g] ? __builtin_amdgcn_exp2f(-delta) : 1.f;
 #pragma unroll
       for (int d = 0; d < NDT; ++d)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ot[d][r] *= corr;
-      lsum2 *= corr;
+        for (int r = 0; r < 16; ++r) ot[g][d][r] *= corr;
+      lsum2[g] *= corr;
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[r] -= delta;
-      m_ref += delta;
-      counted = counted || (mxx > NEG_INF);
+      m_ref[g] += delta;
+      counted[g] = counted[g] || (mxx > NEG_INF);
     }
   };
+  auto frame = [&](f32x16_t (&st)[NQ], int kt, int t, auto masked_c) __attribute__((always_inline)) {
+#pragma unroll
+    for (int g = 0; g < NQ; ++g) frame1(st[g], g, kt, t, masked_c);
+  };
   // block 2 of a half step: P = exp2(s - m_ref), row sums, pack, O^T += V^T · P^T   (+ the next half's S^T chain, see the loop)
-  auto finish = [&](f32x16_t& st, int so, int kt, int t) __attribute__((always_inline)) {
+  auto finish = [&](f32x16_t (&st)[NQ], int so, int kt, int t) __attribute__((always_inline)) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) st[r] = __builtin_amdgcn_exp2f(st[r]);
+    for (int g = 0; g < NQ; ++g) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r) lsum2 += f32x2_t{st[2 * r], st[2 * r + 1]};   // v_pk_add_f32
+      for (int r = 0; r < 16; ++r) st[g][r] = __builtin_amdgcn_exp2f(st[g][r]);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) lsum2[g] += f32x2_t{st[g][2 * r], st[g][2 * r + 1]};   // v_pk_add_f32
+    }
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
-      bf16x8_t pf;
+      bf16x8_t pf[NQ];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int r = 8 * s2 + j;
-        float pv = st[r];
-        if constexpr (DROP) {
-          const unsigned key = (unsigned)(kt * 64 + 32 * t + 8 * (r >> 2) + 4 * hh + (r & 3));
-          pv = drop_keep(p.drop, drop_rh, key) ? pv * p.drop.inv_keep : 0.f;
+      for (int g = 0; g < NQ; ++g)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int r = 8 * s2 + j;
+          float pv = st[g][r];
+          if constexpr (DROP) {
+            const unsigned key = (unsigned)(kt * 64 + 32 * t + 8 * (r >> 2) + 4 * hh + (r & 3));
+            pv = drop_keep(p.drop, drop_rh[g], key) ? pv * p.drop.inv_keep : 0.f;
+          }
+          pf[g][j] = (__bf16)pv;
         }
-        pf[j] = (__bf16)pv;
-      }
 #pragma unroll
       for (int d = 0; d < NDT; ++d) {
         const int roff = so + (32 * t + 16 * s2) * PITCH;
         const bf16x8_t vf = tr_frag2a(v_lo[d] + (unsigned)roff, v_hi[d] + (unsigned)roff);
-        ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, ot[d], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < NQ; ++g) ot[g][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[g], ot[g][d], 0, 0, 0);
       }
     }
   };
@@ -235,13 +261,13 @@ __global__ __launch_bounds__(256, (D == 64) ? 3 : 2) void attn_fwd_kernel(AttnFw
     __builtin_amdgcn_s_barrier();
   };
 
-  f32x16_t sa, sb;   // raw scores of the half in progress / the half issued ahead
+  f32x16_t sa[NQ], sb[NQ];   // raw scores of the half in progress / the half issued ahead
   // Leading tiles that need no mask code: whole inside Sk, left of the causal edge, no key bias.  They run in a main loop
   // unrolled over the ring (every stage offset is then a compile-time constant: the 12 swizzled fragment bases of a lane take
   // immediate offsets instead of two VALU adds per LDS read — 52 of the 226 VALU instructions of a wave-tile, in a loop that
   // is VALU-issue bound) and instantiated without the mask branch; the leftover and masked tiles take the rolled loop.
   int n_plain = p.kbias ? 0 : p.Sk / 64;
-  if (p.causal && 2 * bx < n_plain) n_plain = 2 * bx;
+  if (p.causal && (QB / 64) * bx < n_plain) n_plain = (QB / 64) * bx;
   if (nkt < n_plain) n_plain = nkt;
   constexpr int STG = Cfg::STAGE;
   int kt = 0;
@@ -310,20 +336,21 @@ __global__ __launch_bounds__(256, (D == 64) ? 3 : 2) void attn_fwd_kernel(AttnFw
 
   // ---- normalise; O goes out through LDS as whole rows (the ring is free: every DMA has landed and been consumed) ----
   __builtin_amdgcn_s_barrier();   // all waves are past their last reads of the ring
-  char* obuf = smem + wid * (32 * OP);
-  {
-    const float lsum = lsum2[0] + lsum2[1];
+  char* obuf = smem + wid * (32 * NQ * OP);
+#pragma unroll
+  for (int g = 0; g < NQ; ++g) {
+    const float lsum = lsum2[g][0] + lsum2[g][1];
     const float l_tot = lsum + __shfl_xor(lsum, 32, 64);
     const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
-    if (p.lse2 && hh == 0 && qrow < p.Sq)
-      p.lse2[((size_t)b * p.H + head) * p.Sq + qrow] = l_tot > 0.f ? m_ref + __builtin_amdgcn_logf(l_tot) : NEG_INF;
+    if (p.lse2 && hh == 0 && qrow[g] < p.Sq)
+      p.lse2[((size_t)b * p.H + head) * p.Sq + qrow[g]] = l_tot > 0.f ? m_ref[g] + __builtin_amdgcn_logf(l_tot) : NEG_INF;
 #pragma unroll
     for (int d = 0; d < NDT; ++d)
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int col = 32 * d + 8 * c + 4 * hh;
-        *(uint2*)(obuf + l31 * OP + col * 2) = make_uint2(pack_bf16x2(ot[d][4 * c] * inv, ot[d][4 * c + 1] * inv),
-                                                          pack_bf16x2(ot[d][4 * c + 2] * inv, ot[d][4 * c + 3] * inv));
+        *(uint2*)(obuf + (32 * g + l31) * OP + col * 2) = make_uint2(pack_bf16x2(ot[g][d][4 * c] * inv, ot[g][d][4 * c + 1] * inv),
+                                                                     pack_bf16x2(ot[g][d][4 * c + 2] * inv, ot[g][d][4 * c + 3] * inv));
       }
   }
   // (each wave reads back only what it wrote: no barrier, the compiler's lgkmcnt wait orders the LDS accesses of one wave)
@@ -334,9 +361,9 @@ __global__ __launch_bounds__(256, (D == 64) ? 3 : 2) void attn_fwd_kernel(AttnFw
     const int r_in = lane / CPR, ch = lane % CPR;
     if (lane < RPI * CPR) {
 #pragma unroll
-      for (int it = 0; it < 32 / RPI + (32 % RPI ? 1 : 0); ++it) {
+      for (int it = 0; it < 32 * NQ / RPI + (32 * NQ % RPI ? 1 : 0); ++it) {
         const int row = it * RPI + r_in;
-        if (row < 32) {
+        if (row < 32 * NQ) {
           const i32x4_t v = *(const i32x4_t*)(obuf + row * OP + ch * 16);
           const int qr = q0 + row;
           const int off = (qr < p.Sq) ? ((b * p.Sq + qr) * p.ldo + head * D + ch * 8) * 2 : -1;
@@ -347,11 +374,11 @@ __global__ __launch_bounds__(256, (D == 64) ? 3 : 2) void attn_fwd_kernel(AttnFw
   }
 }
 
-template <int D, bool DROP>
-int launch_attn_fwd(const AttnFwdArgs& a, hipStream_t stream) {
+template <int D, bool DROP, int NQ>
+int launch_attn_fwd_nq(const AttnFwdArgs& a, hipStream_t stream) {
   using Cfg = AttnCfg<D>;
-  auto kern = attn_fwd_kernel<D, DROP>;
-  constexpr int OBUF = 4 * 32 * (2 * D + 16);
+  auto kern = attn_fwd_kernel<D, DROP, NQ>;
+  constexpr int OBUF = 4 * 32 * NQ * (2 * D + 16);
   constexpr int LDS = Cfg::NSTAGE * Cfg::STAGE > OBUF ? Cfg::NSTAGE * Cfg::STAGE : OBUF;
   static DevOnce attr_set;
   if (attr_set.need()) {
@@ -359,8 +386,19 @@ int launch_attn_fwd(const AttnFwdArgs& a, hipStream_t stream) {
       return LC2IS_ERR_LAUNCH;
     attr_set.done();
   }
-  hipLaunchKernelGGL(kern, dim3(((a.Sq + 127) / 128) * a.H * a.B), dim3(256), LDS, stream, a);
+  hipLaunchKernelGGL(kern, dim3(((a.Sq + 128 * NQ - 1) / (128 * NQ)) * a.H * a.B), dim3(256), LDS, stream, a);
   return lc2is_check_launch();
+}
+
+// 64 queries per wave (NQ = 2) where it measured faster (see the table in DESIGN.md); LC2IS_ATTN_FWD_NQ=1|2 forces one form (A/B)
+template <int D, bool DROP>
+int launch_attn_fwd(const AttnFwdArgs& a, hipStream_t stream) {
+  static const int forced = [] { const char* e = getenv("LC2IS_ATTN_FWD_NQ"); return e ? atoi(e) : 0; }();
+  const int nq = forced == 1 || forced == 2 ? forced : 1;
+  if constexpr (D <= 96) {
+    if (nq == 2) return launch_attn_fwd_nq<D, DROP, 2>(a, stream);
+  }
+  return launch_attn_fwd_nq<D, DROP, 1>(a, stream);
 }
 
 }  // namespace
