@@ -97,7 +97,7 @@ __device__ __forceinline__ float dot8(const i32x4_t& a, const i32x4_t& b) {
 constexpr int LC2IS_DQ2_WAVES = 3;      // waves per SIMD the dQ kernel is compiled for at D = 64 (2 measured no slower)
 constexpr int LC2IS_DQ2_DP_AHEAD = 1;   // the dP^T chain of the next half tile is issued ahead together with its S^T chain (16 more live registers)
 template <int D, bool DROP = false>
-__global__ __launch_bounds__(256, (D == 64) ? (DROP ? LC2IS_DQ2_WAVES : 2) : (D <= 96 ? 2 : 1)) void attn_bwd_dq2_kernel(AttnBwdArgs p) {
+__global__ __launch_bounds__(256, (D == 64) ? LC2IS_DQ2_WAVES : (D <= 96 ? 2 : 1)) void attn_bwd_dq2_kernel(AttnBwdArgs p) {
   using Cfg = AttnCfg<D>;
   constexpr int PITCH = Cfg::PITCH, NSTAGE = Cfg::NSTAGE, PD = NSTAGE - 1, STG = Cfg::STAGE;
   constexpr int NKS = D / 16, NDT = D / 32;
@@ -263,51 +263,6 @@ __global__ __launch_bounds__(256, (D == 64) ? (DROP ? LC2IS_DQ2_WAVES : 2) : (D 
       }
     }
   };
-  // Interior half step with the order pinned (round 4, as in the dK/dV kernel): the S^T / dP^T chains of half (son, tn) are issued
-  // BETWEEN the exp2 / dS arithmetic of half (so, t) — one chain MFMA, then two scores —, every LDS fragment read ahead of the region.
-  // An in-order wave runs the matrix pipe and the VALU side by side only when they alternate in program order.
-  constexpr bool DQ2_IL = !DROP && D == 64;
-  auto half_il = [&](int son, int tn, f32x16_t& sn, f32x16_t& dn, f32x16_t& sc, f32x16_t& dc, int so, int t) __attribute__((always_inline)) {
-    bf16x8_t kfr[NKS], vfr[NKS], ktf[2][NDT];
-#pragma unroll
-    for (int s = 0; s < NKS; ++s) {
-      kfr[s] = lds_read_b128(k_row[s] + (unsigned)(son + 32 * tn * PITCH));
-      vfr[s] = lds_read_b128(k_row[s] + (unsigned)(son + Cfg::TILE + 32 * tn * PITCH));
-    }
-#pragma unroll
-    for (int s2i = 0; s2i < 2; ++s2i)
-#pragma unroll
-      for (int d = 0; d < NDT; ++d) {
-        const unsigned roff = (unsigned)(so + (32 * t + 16 * s2i) * PITCH);
-        ktf[s2i][d] = tr_frag2a(t_lo[d] + roff, t_hi[d] + roff);
-      }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { sn[r] = 0.f; dn[r] = 0.f; }
-    const f32x2_t sc2 = {p.scale_log2, p.scale_log2}, nl2 = {-lse, -lse}, dl2 = {delta, delta};
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-#pragma unroll
-      for (int m = i * 2 * NKS / 8; m < (i + 1) * 2 * NKS / 8; ++m) {
-        if (m & 1) dn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[m >> 1], dof[m >> 1], dn, 0, 0, 0);
-        else       sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[m >> 1], qf[m >> 1], sn, 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      const int r = 2 * i;
-      const f32x2_t s2 = f32x2_t{sc[r], sc[r + 1]} * sc2 + nl2;
-      const f32x2_t pr = {__builtin_amdgcn_exp2f(s2[0]), __builtin_amdgcn_exp2f(s2[1])};
-      const f32x2_t ds = pr * (f32x2_t{dc[r], dc[r + 1]} - dl2);
-      dc[r] = ds[0];
-      dc[r + 1] = ds[1];
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int s2i = 0; s2i < 2; ++s2i) {
-      const bf16x8_t dsf = pack8(dc, 8 * s2i);
-#pragma unroll
-      for (int d = 0; d < NDT; ++d) dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[s2i][d], dsf, dq[d], 0, 0, 0);
-    }
-  };
   auto land = [&]() __attribute__((always_inline)) {
     wait_vm0();
     __builtin_amdgcn_s_barrier();
@@ -325,22 +280,16 @@ __global__ __launch_bounds__(256, (D == 64) ? (DROP ? LC2IS_DQ2_WAVES : 2) : (D 
     auto step = [&](int kt, auto so_c, auto son_c, auto sreq_c) __attribute__((always_inline)) {
       const int so = so_c, son = son_c, sreq = sreq_c;
       if (wave_active) {
-        if constexpr (DQ2_IL) half_il(so, 1, sb, db, sa, da, so, 0);
-        else {
-          issue(so, 1, sb, db);
-          finish(sa, da, so, kt, 0, no);
-        }
+        issue(so, 1, sb, db);
+        finish(sa, da, so, kt, 0, no);
       }
       __builtin_amdgcn_sched_barrier(0);   // a half step is the scheduling region: without the fences hipcc hoists the LDS reads of
       land();                              // later half steps to the top of the unrolled triple and spills
       if (kt + 2 < nkt) request(kt + 2, sreq);
       __builtin_amdgcn_sched_barrier(0);
       if (wave_active) {
-        if constexpr (DQ2_IL) half_il(son, 0, sa, da, sb, db, so, 1);
-        else {
-          issue(son, 0, sa, da);
-          finish(sb, db, so, kt, 1, no);
-        }
+        issue(son, 0, sa, da);
+        finish(sb, db, so, kt, 1, no);
       }
       __builtin_amdgcn_sched_barrier(0);
     };
