@@ -53,8 +53,8 @@ SAMPLE_EVERY = 4   # HIP-event pairs around the dominant kernel on every 4th tim
 
 
 class GemmTimer:
-    """HIP-event timing of every call that runs the dominant kernel — the 256x256 LDS-DMA NT GEMM (gemm_nt_dma_kernel<256,256,2,4>
-    and its persistent forms gemm_nt_persist2_kernel / gemm_nt_pp_kernel, same tile algebra), i.e. the NT GEMMs
+    """HIP-event timing of every call that runs the dominant kernel — the large-tile LDS-DMA NT GEMM (gemm_nt_dma_kernel<256,256,2,4>,
+    its persistent forms gemm_nt_persist2_kernel / gemm_nt_pp_kernel and the 256x384 form gemm_nt_w384_kernel, same tile algebra), i.e. the NT GEMMs
     with >= 1024 128x128 tiles of output and N % 256 == 0 (the dispatch rule of lc2is_gemm_nt_bf16) — recorded on the
     stream the kernel is launched on.  (The small GEMMs of the text tower / decoder use other tile kernels and overlap
     the vision tower on a side stream; they are not part of this kernel's roofline.)"""
@@ -323,7 +323,7 @@ def main():
                        "parallelism": f"dp{world}", "params_M": round(ts.arena.numel / 1e6, 2)},
             "final_loss": loss_val,
             **({"diagnostic": "LC2IS_BENCH_CACHED_TEXT: the text tower is skipped — NOT a benchmark result"} if diag_cached_text else {}),
-            "roofline": {"bound": "mfma", "kernel": "256x256 LDS-DMA NT GEMM: gemm_nt_dma_kernel<256,256,2,4,*> + its persistent ping-pong form gemm_nt_pp_kernel<*> (every launch of each 4th timed step)",
+            "roofline": {"bound": "mfma", "kernel": "large-tile LDS-DMA NT GEMM family: gemm_nt_pp_kernel<*> (persistent ping-pong 256x256), gemm_nt_w384_kernel (256x384, N = 768), gemm_nt_dma_kernel<256,256,2,4,*> (every launch of each 4th timed step)",
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": ref.get("dominant_kernel_hbm_bytes_per_launch"),
                          "traffic_source": (f"profiles/roofline_ref.json: {ref.get('dominant_kernel_hbm_source')}"

@@ -590,6 +590,170 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_dma_kernel(Gemm
   gemm_epilogue<TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lane);
 }
 
+// ---- 256x384 tile for the N = 768 problems (cfg 16, round 4) -------------------------------------------------------------------
+// The residual-stream GEMMs of the ViT-B tower (out-proj, fc2 and the dgrads into the fp32 stream: N = 768, M = B x 1025) are 3
+// column tiles of 256: 384 tiles after the ragged-row peel = 1.5 rounds of the 256 CUs.  With 384-wide tiles they are 2 x 128 =
+// 256 tiles: EXACTLY one round.  8 waves (2 x 4), 128 x 96 per wave: 192 accumulator registers; the A fragments of a K sub-step
+// are read in two halves of four so that the loop fits 256 registers without scratch; (128 + 96) / (128 x 96) LDS bytes per MFMA
+// column instead of (128 + 64) / (128 x 64): 22 % fewer fragment reads per FLOP.  Both stages take the CU's whole 160 KiB of LDS;
+// the epilogue's patches overlay them.  Same K order as every other tile shape: bitwise equal to tile_cfg 4.
+// fp32-only output (bias + fp32 residual -> fp32), through LDS in whole 384-byte row segments, 32 rows at a time.
+__global__ __launch_bounds__(512) void gemm_nt_w384_kernel(GemmNtArgs p) {
+  constexpr int BM = 256, BN = 384, WAVES_N = 4, NWAVE = 8, BK = 64;
+  constexpr int WM = 128, WN = 96, TM = 8, TN = 6;
+  constexpr int A_PIECES = BM / 8 / NWAVE, W_PIECES = BN / 8 / NWAVE;   // 4 + 6 one-KiB pieces per wave and stage
+  constexpr int STAGE = (BM + BN) * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+  const int ntn = p.N / BN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+  const unsigned a_bytes = (unsigned)p.M * (unsigned)p.lda * 2u, w_bytes = (unsigned)p.N * (unsigned)p.ldw * 2u;
+
+  const int lrow = lane >> 3, lch = (lane & 7) ^ (lane >> 3);
+  int a_goff[A_PIECES], w_goff[W_PIECES];
+#pragma unroll
+  for (int j = 0; j < A_PIECES; ++j) a_goff[j] = ((m0 + 8 * (wid * A_PIECES + j) + lrow) * p.lda + lch * 8) * 2;
+#pragma unroll
+  for (int j = 0; j < W_PIECES; ++j) w_goff[j] = ((n0 + 8 * (wid * W_PIECES + j) + lrow) * p.ldw + lch * 8) * 2;
+
+  f32x4_t acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, g = lane >> 4, sw = lane & 7;
+  const int x_frag = (wm * WM + frow) * 128;
+  const int w_frag = BM * 128 + (wn * WN + frow) * 128;
+  const int kc_off0 = ((0 + g) ^ sw) << 4, kc_off1 = ((4 + g) ^ sw) << 4;
+  const int nk = p.K / BK;
+
+  dma_stage<BM, A_PIECES, W_PIECES>(p.A, a_bytes, p.W, w_bytes, smem, wid, a_goff, w_goff, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* cur = smem + (kt & 1) * STAGE;
+    if (kt + 1 < nk)
+      dma_stage<BM, A_PIECES, W_PIECES>(p.A, a_bytes, p.W, w_bytes, smem + ((kt + 1) & 1) * STAGE, wid, a_goff, w_goff,
+                                        (kt + 1) * BK * 2);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int ko = ks ? kc_off1 : kc_off0;
+      bf16x8_t wf[TN];
+#pragma unroll
+      for (int i = 0; i < TN; ++i) wf[i] = *(const bf16x8_t*)(cur + w_frag + i * 16 * 128 + ko);
+#pragma unroll
+      for (int jh = 0; jh < TM; jh += 4) {
+        bf16x8_t xf[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xf[j] = *(const bf16x8_t*)(cur + x_frag + (jh + j) * 16 * 128 + ko);
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][jh + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][jh + j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);   // (keeps the second half's fragment reads out of the first half: 256 registers, no scratch)
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: out = acc + bias (+ fp32 residual), 32 rows x 96 columns of the wave at a time through its LDS patch ----
+  constexpr int PITCH = WN * 4 + 16;   // 400 B: 16 lanes of a ds_write_b128 group land on 16 distinct bank quads
+  char* patch = smem + wid * (32 * PITCH);
+  const int nw = n0 + wn * WN;
+  const __amdgpu_buffer_rsrc_t rsR = make_rsrc(p.resid, p.resid ? (unsigned)p.M * (unsigned)p.ldr * 4u : 0u);
+  const __amdgpu_buffer_rsrc_t rsO = make_rsrc(p.out_f32, (unsigned)p.M * (unsigned)p.ldf * 4u);
+  constexpr int OOB = 0x7fffffff;
+  // flush mapping: 8 rows x 24 sixteen-byte chunks = 3 wave instructions; element k * 64 + lane -> (row, chunk)
+  int frow8[3], fch[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int e = k * 64 + lane;
+    frow8[k] = e / 24;
+    fch[k] = e % 24;
+  }
+  f32x4_t bvs[TN];
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int n = nw + i * 16 + g * 4;
+    bvs[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (p.bias && n < p.N) bvs[i] = *(const f32x4_t*)(p.bias + n);
+  }
+#pragma unroll
+  for (int jg = 0; jg < TM / 2; ++jg) {
+    const int mrow0 = m0 + wm * WM + jg * 32;
+    if (mrow0 >= p.M) break;   // wave-uniform
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int jl = 0; jl < 2; ++jl)
+        *(f32x4_t*)(patch + (jl * 16 + frow) * PITCH + (i * 16 + g * 4) * 4) = acc[i][jg * 2 + jl] + bvs[i];
+#pragma unroll
+    for (int hq = 0; hq < 12; hq += 6) {
+      i32x4_t rv[6];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const int row = ((hq + q) / 3) * 8 + frow8[q % 3], col = nw + fch[q % 3] * 4;
+        rv[q] = __builtin_amdgcn_raw_buffer_load_b128(rsR, col < p.N ? ((mrow0 + row) * p.ldr + col) * 4 : OOB, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const int row = ((hq + q) / 3) * 8 + frow8[q % 3], col = nw + fch[q % 3] * 4;
+        const f32x4_t v = *(const f32x4_t*)(patch + row * PITCH + fch[q % 3] * 16) + __builtin_bit_cast(f32x4_t, rv[q]);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, v), rsO, col < p.N ? ((mrow0 + row) * p.ldf + col) * 4 : OOB, 0, 2);   // nt
+      }
+    }
+  }
+}
+
+// ---- ragged-row tail (cfg 17, round 4) ------------------------------------------------------------------------------------------
+// The <= 64 rows that the exact-round plans peel off (B x 1025 tokens: 32 rows) used to go through the 64x64 register-staged kernel:
+// 12 blocks walking K = 3072 in 48 latency-bound steps = 22 us, as much as the 256x384 plan saves.  Here ONE WAVE owns 16 rows x 16
+// columns and the whole K: both operands come straight from global memory in the MFMA fragment layout (a lane's 8 consecutive K
+// elements are 16 contiguous bytes of a row), PD K chunks of 32 in flight, no LDS, no barrier.  Same MFMA, same operand roles and the
+// same sequential order over K as the tile kernels: bitwise equal to tile_cfg 4.  fp32-only output (bias + fp32 residual).
+template <int PD>
+__global__ __launch_bounds__(64) void gemm_nt_rows_kernel(GemmNtArgs p) {
+  const int lane = threadIdx.x, frow = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+  constexpr int OOB = 0x7fffffff;
+  const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, (unsigned)p.M * (unsigned)p.lda * 2u);
+  const __amdgpu_buffer_rsrc_t rsW = make_rsrc(p.W, (unsigned)p.N * (unsigned)p.ldw * 2u);
+  const bool n_ok = n0 + frow < p.N;
+  const int a_off = ((m0 + frow) * p.lda + g * 8) * 2;   // rows >= M fall outside num_records: zeros
+  const int w_off = n_ok ? ((n0 + frow) * p.ldw + g * 8) * 2 : OOB;
+  const int kbytes = p.K * 2;
+  bf16x8_t wa[PD], xa[PD];
+#pragma unroll
+  for (int i = 0; i < PD; ++i) {
+    const int kb = i * 64;
+    wa[i] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rsW, kb < kbytes ? w_off + kb : OOB, 0, 0));
+    xa[i] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rsA, kb < kbytes ? a_off + kb : OOB, 0, 0));
+  }
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  for (int kb0 = 0; kb0 < kbytes; kb0 += PD * 64) {
+#pragma unroll
+    for (int i = 0; i < PD; ++i) {
+      if (kb0 + i * 64 < kbytes)   // (uniform; chunks past K are never accumulated: the sum stays the tile kernels' sum)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[i], xa[i], acc, 0, 0, 0);
+      const int kb = kb0 + (i + PD) * 64;
+      wa[i] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rsW, kb < kbytes ? w_off + kb : OOB, 0, 0));
+      xa[i] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rsA, kb < kbytes ? a_off + kb : OOB, 0, 0));
+    }
+  }
+  const int m = m0 + frow, n = n0 + g * 4;
+  if (m < p.M && n < p.N) {
+    f32x4_t v = acc;
+    if (p.bias) v += *(const f32x4_t*)(p.bias + n);
+    if (p.resid) v += *(const f32x4_t*)(p.resid + (size_t)m * p.ldr + n);
+    *(f32x4_t*)(p.out_f32 + (size_t)m * p.ldf + n) = v;
+  }
+}
+
 // ---- persistent form with counted waits across the tile seam (cfg 13) ------------------------------------------------------
 // As cfg 11, but the barrier that publishes the next tile's prefetched first stage no longer drains the epilogue's stores: gfx9
 // retires loads and stores of a wave in order through ONE counter, so with the first-stage DMAs issued BEFORE the epilogue and
@@ -900,6 +1064,25 @@ int launch_dma(const GemmNtArgs& a, hipStream_t stream) {
   return lc2is_check_launch();
 }
 
+int launch_w384(const GemmNtArgs& a, hipStream_t stream) {
+  constexpr int LDS = 2 * (256 + 384) * 128;   // 160 KiB: the whole CU
+  if (a.N % 384 || a.out_bf16 || a.aux_out || a.aux_in || !a.out_f32 || a.act != LC2IS_ACT_NONE) return LC2IS_ERR_UNSUPPORTED;
+  static DevOnce attr_set;
+  if (attr_set.need()) {
+    if (hipFuncSetAttribute((const void*)gemm_nt_w384_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+      return LC2IS_ERR_LAUNCH;
+    attr_set.done();
+  }
+  hipLaunchKernelGGL(gemm_nt_w384_kernel, dim3(((a.M + 255) / 256) * (a.N / 384)), dim3(512), LDS, stream, a);
+  return lc2is_check_launch();
+}
+
+int launch_rows(const GemmNtArgs& a, hipStream_t stream) {
+  if (a.M > 64 || a.out_bf16 || a.aux_out || a.aux_in || !a.out_f32 || a.act != LC2IS_ACT_NONE || a.N % 4) return LC2IS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(gemm_nt_rows_kernel<16>, dim3((a.N + 15) / 16, (a.M + 15) / 16), dim3(64), 0, stream, a);
+  return lc2is_check_launch();
+}
+
 template <int ACT>
 int launch_persist2_act(const GemmNtArgs& a, hipStream_t stream) {
   constexpr int LDS = (256 + 256) * 128 + 8 * 64 * 144;
@@ -978,6 +1161,8 @@ int launch_by_cfg(const GemmNtArgs& a_in, int cfg, hipStream_t stream) {
       }
     case 13: return launch_persist2(a, stream);
     case 15: return launch_pp(a, stream);
+    case 16: return f32_staged ? launch_w384(a, stream) : LC2IS_ERR_UNSUPPORTED;
+    case 17: return launch_rows(a, stream);
     default: return LC2IS_ERR_UNSUPPORTED;
   }
 }
@@ -1053,9 +1238,12 @@ extern "C" int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw
   // (B x 1025 tokens: 32 rows) are peeled off into a small-tile launch when that saves a whole round of tiles.
   int best_cfg = 0, best_main = M;
   double best_cost = 1e300;
+  // cfg 16 (256x384 tiles, fp32-only output): N = 768 at M = 128 x 256 is exactly one round instead of 1.5 (LC2IS_GEMM_W384=0: off)
+  static const bool use_w384 = !(getenv("LC2IS_GEMM_W384") && atoi(getenv("LC2IS_GEMM_W384")) == 0);
   for (int split = 0; split < 2; ++split)
-    for (int c : {4}) {   // (one candidate tile shape: 128x384 measured ~45 % slower per flop and left the library)
-      const int bm = 256, bn = 256;
+    for (int c : {4, 16}) {   // (128x384 measured ~45 % slower per flop and left the library)
+      const int bm = 256, bn = c == 16 ? 384 : 256;
+      if (c == 16 && !(use_w384 && a.staged_epi == 2)) continue;
       if (N % bn) continue;
       const int r = M % bm;
       if (split && (r == 0 || r > 64 || M <= bm)) continue;
@@ -1079,7 +1267,7 @@ extern "C" int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw
   if (a.out_bf16) tail.out_bf16 = a.out_bf16 + m0 * ldo;
   if (a.out_f32) tail.out_f32 = a.out_f32 + m0 * ldf;
   if (a.aux_out) tail.aux_out = a.aux_out + m0 * ldy;
-  return launch_by_cfg(tail, 3, stream);
+  return launch_by_cfg(tail, best_cfg == 16 ? 17 : 3, stream);
 }
 
 // Strided-batched plain product: out[b] = A[b] (M x K) . W[b]^T (N x K), b = 0..batch-1, in ONE launch (blockIdx.y = b).

@@ -163,6 +163,68 @@ def test_gemm_nt_ping_pong_is_bitwise_equal(dev, M, N, K):
     assert _rel(ops.gemm_nt(a, w, bias, tile_cfg=15)[0].float(), ref) < 4e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(2048, 768, 768), (2050, 768, 128), (300, 384, 64), (4100, 1152, 320), (32768, 768, 192)])
+def test_gemm_nt_w384_is_bitwise_equal(dev, M, N, K):
+    """tile_cfg 16 — 256x384 tiles (8 waves x 128x96, fp32-only output through LDS in 384-byte row segments; the whole 160 KiB of
+    LDS for the two stages) — against tile_cfg 4 on the residual-stream form out = resid + a.w^T + bias: same K order, so bitwise
+    equal; ragged rows (2050, 300, 4100) exercise the range-checked residual loads / stores, N = 384 / 1152 one and three column
+    tiles, K = 64 a single K tile.  Also without bias / residual (the dgrads into the fp32 stream)."""
+    from lc2is_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    a = _bf(torch.randn(M, K, generator=g)).to(dev)
+    w = _bf(torch.randn(N, K, generator=g) * 0.1).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    resid = torch.randn(M, N, generator=g).to(dev)
+    for rep in range(2):
+        _, f4, _ = ops.gemm_nt(a, w, bias, resid=resid, out_bf16=False, out_f32=True, tile_cfg=4)
+        _, f16, _ = ops.gemm_nt(a, w, bias, resid=resid, out_bf16=False, out_f32=True, tile_cfg=16)
+        assert torch.equal(f4, f16)
+        _, g4, _ = ops.gemm_nt(a, w, None, out_bf16=False, out_f32=True, tile_cfg=4)
+        _, g16, _ = ops.gemm_nt(a, w, None, out_bf16=False, out_f32=True, tile_cfg=16)
+        assert torch.equal(g4, g16)
+    inplace = resid.clone()   # the residual stream updated in place (out_f32 is resid)
+    ops.gemm_nt(a, w, bias, resid=inplace, out_bf16=False, out_f32=inplace, tile_cfg=16)
+    assert torch.equal(inplace, f4)
+    ref = a.double() @ w.double().T + bias.double() + resid.double()
+    assert _rel(f16, ref) < 2e-6 * (K ** 0.5)  # fp32 accumulate of exact bf16 products
+
+
+@pytest.mark.parametrize("M,N,K", [(32, 768, 3072), (64, 768, 768), (17, 200, 64), (1, 16, 320), (48, 1152, 2304)])
+def test_gemm_nt_rows_tail_is_bitwise_equal(dev, M, N, K):
+    """tile_cfg 17 — the ragged-row tail of the exact-round plans: one wave per 16 x 16 outputs and the whole K, operands straight
+    from global memory in the MFMA fragment layout, 16 K chunks in flight — against tile_cfg 4 (same MFMA, same operand roles, same
+    sequential K order: bitwise equal).  K = 64 and 320 are not multiples of the 512-element prefetch window (chunks past K must not be
+    accumulated), N = 200 has a ragged last column group, M = 1 / 17 ragged row fragments."""
+    from lc2is_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    a = _bf(torch.randn(M, K, generator=g)).to(dev)
+    w = _bf(torch.randn(N, K, generator=g) * 0.1).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    resid = torch.randn(M, N, generator=g).to(dev)
+    _, f4, _ = ops.gemm_nt(a, w, bias, resid=resid, out_bf16=False, out_f32=True, tile_cfg=4)
+    _, f17, _ = ops.gemm_nt(a, w, bias, resid=resid, out_bf16=False, out_f32=True, tile_cfg=17)
+    assert torch.equal(f4, f17)
+    _, g4, _ = ops.gemm_nt(a, w, None, out_bf16=False, out_f32=True, tile_cfg=4)
+    _, g17, _ = ops.gemm_nt(a, w, None, out_bf16=False, out_f32=True, tile_cfg=17)
+    assert torch.equal(g4, g17)
+
+
+def test_gemm_nt_auto_plan_picks_exact_round_and_matches(dev):
+    """M = 32 800, N = 768 (the residual-stream GEMMs of the headline step): the automatic plan is 256 tiles of 256x384 + the row
+    tail; bitwise equal to the single-launch 256x256 plan, residual updated in place as the modules do."""
+    from lc2is_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(5)
+    M, N, K = 32800, 768, 768
+    a = _bf(torch.randn(M, K, generator=g)).to(dev)
+    w = _bf(torch.randn(N, K, generator=g) * 0.1).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    resid = torch.randn(M, N, generator=g).to(dev)
+    _, f4, _ = ops.gemm_nt(a, w, bias, resid=resid, out_bf16=False, out_f32=True, tile_cfg=4)
+    x = resid.clone()
+    ops.gemm_nt(a, w, bias, resid=x, out_bf16=False, out_f32=x, tile_cfg=0)
+    assert torch.equal(x, f4)
+
+
 @pytest.mark.parametrize("N,K", [(3072, 128), (768, 192), (2304, 128)])
 def test_gemm_nt_auto_plan_ragged_rows(dev, N, K):
     """M = 64*256 + 32 rows (the B x 1025-token shape): the automatic plan peels the ragged rows into a small-tile

@@ -5,7 +5,7 @@ gemm_nt_dma_kernel<256, 256, 2, 4, *> and of its persistent forms gemm_nt_persis
 and tallies 128-B requests at 64 B on gfx950 -> bytes = 2 x 1000 x FETCH_SIZE; WRITE_SIZE is KB, exact."""
 import collections, csv, json, re, sys
 
-DOM = ("gemm_nt_dma_kernel<256, 256, 2, 4,", "gemm_nt_persist2_kernel<", "gemm_nt_pp_kernel<")   # the 256x256 LDS-DMA NT GEMM: plain, persistent and ping-pong forms
+DOM = ("gemm_nt_dma_kernel<256, 256, 2, 4,", "gemm_nt_persist2_kernel<", "gemm_nt_pp_kernel<", "gemm_nt_w384_kernel")   # the 256x256 LDS-DMA NT GEMM: plain, persistent and ping-pong forms
 
 
 def per_kernel(path, counter):
@@ -45,7 +45,7 @@ def main():
                       "--no-cpu-baseline (two separate passes, tools/prof_pmc.sh)",
            "corrections": "FETCH_SIZE is KB and tallies 128-B requests at 64 B on gfx950: bytes = 2 x 1000 x FETCH_SIZE; "
                           "WRITE_SIZE KB exact (MI355X_MICROARCH.md, HBM section)",
-           "kernel": "gemm_nt_dma_kernel<256, 256, 2, 4, *> + gemm_nt_pp_kernel<*> / gemm_nt_persist2_kernel<*> (the 256x256 LDS-DMA NT GEMM, plain and persistent forms, all epilogue instantiations, launch-weighted)", "launches": n,
+           "kernel": "gemm_nt_dma_kernel<256, 256, 2, 4, *> + gemm_nt_pp_kernel<*> / gemm_nt_persist2_kernel<*> + gemm_nt_w384_kernel (the large-tile LDS-DMA NT GEMM: 256x256 plain / persistent, 256x384; all epilogue instantiations, launch-weighted)", "launches": n,
            "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr}
     json.dump(out, open(sys.argv[3] + "_hbm.json", "w"), indent=1)
     print(json.dumps(out))

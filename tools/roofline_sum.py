@@ -87,7 +87,7 @@ def main():
         rec = json.load(open(sq))
         out["sq_counters"] = {k: {f: v[f] for f in ("dispatches", "avg_us", "mfma_busy_frac", "clock_ghz", "active", "wait_inst", "wait_any")}
                               for k, v in rec.items()}
-        dom = {k: v for k, v in rec.items() if k.startswith(("gemm_nt_pp_kernel", "gemm_nt_persist2_kernel", "gemm_nt_dma_kernel<256, 256, 2, 4,",
+        dom = {k: v for k, v in rec.items() if k.startswith(("gemm_nt_pp_kernel", "gemm_nt_persist2_kernel", "gemm_nt_w384_kernel", "gemm_nt_dma_kernel<256, 256, 2, 4,",
                                                               "gemm_nt_dma_kernel<256, 256, 2, 4, 1", "gemm_nt_dma_kernel<256, 256, 2, 4, 2",
                                                               "gemm_nt_dma_kernel<256, 256, 2, 4, 3", "gemm_nt_dma_kernel<256, 256, 2, 4, 4"))}
         w = sum(v["dispatches"] * v["avg_us"] for v in dom.values())
