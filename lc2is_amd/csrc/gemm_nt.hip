@@ -715,7 +715,7 @@ __global__ __launch_bounds__(512) void gemm_nt_w384_kernel(GemmNtArgs p) {
 // 12 blocks walking K = 3072 in 48 latency-bound steps = 22 us, as much as the 256x384 plan saves.  Here ONE WAVE owns 16 rows x 16
 // columns and the whole K: both operands come straight from global memory in the MFMA fragment layout (a lane's 8 consecutive K
 // elements are 16 contiguous bytes of a row), PD K chunks of 32 in flight, no LDS, no barrier.  Same MFMA, same operand roles and the
-// same sequential order over K as the tile kernels: bitwise equal to tile_cfg 4.  fp32-only output (bias + fp32 residual).
+// same sequential order over K as the tile kernels, and their unstaged epilogue: bitwise equal to tile_cfg 4 for every activation.
 template <int PD>
 __global__ __launch_bounds__(64) void gemm_nt_rows_kernel(GemmNtArgs p) {
   const int lane = threadIdx.x, frow = lane & 15, g = lane >> 4;
@@ -734,24 +734,18 @@ __global__ __launch_bounds__(64) void gemm_nt_rows_kernel(GemmNtArgs p) {
     wa[i] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rsW, kb < kbytes ? w_off + kb : OOB, 0, 0));
     xa[i] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rsA, kb < kbytes ? a_off + kb : OOB, 0, 0));
   }
-  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  f32x4_t acc[1][1] = {{f32x4_t{0.f, 0.f, 0.f, 0.f}}};
   for (int kb0 = 0; kb0 < kbytes; kb0 += PD * 64) {
 #pragma unroll
     for (int i = 0; i < PD; ++i) {
       if (kb0 + i * 64 < kbytes)   // (uniform; chunks past K are never accumulated: the sum stays the tile kernels' sum)
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[i], xa[i], acc, 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[i], xa[i], acc[0][0], 0, 0, 0);
       const int kb = kb0 + (i + PD) * 64;
       wa[i] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rsW, kb < kbytes ? w_off + kb : OOB, 0, 0));
       xa[i] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rsA, kb < kbytes ? a_off + kb : OOB, 0, 0));
     }
   }
-  const int m = m0 + frow, n = n0 + g * 4;
-  if (m < p.M && n < p.N) {
-    f32x4_t v = acc;
-    if (p.bias) v += *(const f32x4_t*)(p.bias + n);
-    if (p.resid) v += *(const f32x4_t*)(p.resid + (size_t)m * p.ldr + n);
-    *(f32x4_t*)(p.out_f32 + (size_t)m * p.ldf + n) = v;
-  }
+  gemm_epilogue<1, 1, 16, 16>(p, acc, m0, n0, 0, 0, lane);   // every epilogue of the tile kernels (same arithmetic, unstaged)
 }
 
 // ---- persistent form with counted waits across the tile seam (cfg 13) ------------------------------------------------------
@@ -1078,7 +1072,7 @@ int launch_w384(const GemmNtArgs& a, hipStream_t stream) {
 }
 
 int launch_rows(const GemmNtArgs& a, hipStream_t stream) {
-  if (a.M > 64 || a.out_bf16 || a.aux_out || a.aux_in || !a.out_f32 || a.act != LC2IS_ACT_NONE || a.N % 4) return LC2IS_ERR_UNSUPPORTED;
+  if (a.M > 64 || a.N % 4) return LC2IS_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(gemm_nt_rows_kernel<16>, dim3((a.N + 15) / 16, (a.M + 15) / 16), dim3(64), 0, stream, a);
   return lc2is_check_launch();
 }
@@ -1198,6 +1192,8 @@ extern "C" int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw
     a.staged_epi = 2;
   int cfg = tile_cfg;
   if (cfg != 0) return launch_by_cfg(a, cfg, stream);
+  // ragged-row tails (<= 64 rows) of the exact-round plans: the one-wave-per-fragment kernel (cfg 17); LC2IS_GEMM_ROWS_TAIL=0: 64x64 tiles
+  static const int tail_cfg = (getenv("LC2IS_GEMM_ROWS_TAIL") && atoi(getenv("LC2IS_GEMM_ROWS_TAIL")) == 0) ? 3 : 17;
   const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
   static const long cfg6_min = getenv("LC2IS_GEMM_CFG6_MIN") ? atol(getenv("LC2IS_GEMM_CFG6_MIN")) : 128;   // (512 and the register-staged 128x128 kernel below it measured 0.8 % slower on config 5)
   if (!(tiles128 >= 1024 && N % 256 == 0)) {
@@ -1230,7 +1226,7 @@ extern "C" int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw
       if (a.aux_in) tail.aux_in = a.aux_in + m0 * ldx;
       if (a.out_bf16) tail.out_bf16 = a.out_bf16 + m0 * ldo;
       if (a.aux_out) tail.aux_out = a.aux_out + m0 * ldy;
-      return launch_by_cfg(tail, 3, stream);
+      return launch_by_cfg(tail, tail_cfg, stream);
     }
     return launch_by_cfg(a, pcfg, stream);
   }
@@ -1267,7 +1263,7 @@ extern "C" int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw
   if (a.out_bf16) tail.out_bf16 = a.out_bf16 + m0 * ldo;
   if (a.out_f32) tail.out_f32 = a.out_f32 + m0 * ldf;
   if (a.aux_out) tail.aux_out = a.aux_out + m0 * ldy;
-  return launch_by_cfg(tail, best_cfg == 16 ? 17 : 3, stream);
+  return launch_by_cfg(tail, tail_cfg, stream);
 }
 
 // Strided-batched plain product: out[b] = A[b] (M x K) . W[b]^T (N x K), b = 0..batch-1, in ONE launch (blockIdx.y = b).

@@ -189,7 +189,7 @@ def test_gemm_nt_w384_is_bitwise_equal(dev, M, N, K):
     assert _rel(f16, ref) < 2e-6 * (K ** 0.5)  # fp32 accumulate of exact bf16 products
 
 
-@pytest.mark.parametrize("M,N,K", [(32, 768, 3072), (64, 768, 768), (17, 200, 64), (1, 16, 320), (48, 1152, 2304)])
+@pytest.mark.parametrize("M,N,K", [(32, 768, 3072), (64, 768, 768), (17, 200, 64), (1, 16, 320), (48, 1152, 2304), (32, 3072, 768)])
 def test_gemm_nt_rows_tail_is_bitwise_equal(dev, M, N, K):
     """tile_cfg 17 — the ragged-row tail of the exact-round plans: one wave per 16 x 16 outputs and the whole K, operands straight
     from global memory in the MFMA fragment layout, 16 K chunks in flight — against tile_cfg 4 (same MFMA, same operand roles, same
@@ -207,6 +207,14 @@ def test_gemm_nt_rows_tail_is_bitwise_equal(dev, M, N, K):
     _, g4, _ = ops.gemm_nt(a, w, None, out_bf16=False, out_f32=True, tile_cfg=4)
     _, g17, _ = ops.gemm_nt(a, w, None, out_bf16=False, out_f32=True, tile_cfg=17)
     assert torch.equal(g4, g17)
+    # the bf16 epilogues it takes over from the 64x64 kernel in front of the persistent forms (fc1: quick_gelu + saved z; dfc2: x gelu'(z))
+    saved = _bf(torch.randn(M, N, generator=g)).to(dev)
+    o4, _, z4 = ops.gemm_nt(a, w, bias, act=ops.ACT_QUICK_GELU, aux_out=True, tile_cfg=4)
+    o17, _, z17 = ops.gemm_nt(a, w, bias, act=ops.ACT_QUICK_GELU, aux_out=True, tile_cfg=17)
+    assert torch.equal(o4, o17) and torch.equal(z4, z17)
+    d4, _, _ = ops.gemm_nt(a, w, None, act=ops.ACT_DQUICK_GELU, aux_in=saved, tile_cfg=4)
+    d17, _, _ = ops.gemm_nt(a, w, None, act=ops.ACT_DQUICK_GELU, aux_in=saved, tile_cfg=17)
+    assert torch.equal(d4, d17)
 
 
 def test_gemm_nt_auto_plan_picks_exact_round_and_matches(dev):
