@@ -182,6 +182,12 @@ def test_gemm_nt_w384_is_bitwise_equal(dev, M, N, K):
         _, g4, _ = ops.gemm_nt(a, w, None, out_bf16=False, out_f32=True, tile_cfg=4)
         _, g16, _ = ops.gemm_nt(a, w, None, out_bf16=False, out_f32=True, tile_cfg=16)
         assert torch.equal(g4, g16)
+        b4, _, _ = ops.gemm_nt(a, w, bias, tile_cfg=4)     # bf16-only output (the dgrads that feed LayerNorm / attention backward)
+        b16, _, _ = ops.gemm_nt(a, w, bias, tile_cfg=16)
+        assert torch.equal(b4, b16)
+        b4, _, _ = ops.gemm_nt(a, w, None, tile_cfg=4)
+        b16, _, _ = ops.gemm_nt(a, w, None, tile_cfg=16)
+        assert torch.equal(b4, b16)
     inplace = resid.clone()   # the residual stream updated in place (out_f32 is resid)
     ops.gemm_nt(a, w, bias, resid=inplace, out_bf16=False, out_f32=inplace, tile_cfg=16)
     assert torch.equal(inplace, f4)
@@ -231,6 +237,9 @@ def test_gemm_nt_auto_plan_picks_exact_round_and_matches(dev):
     x = resid.clone()
     ops.gemm_nt(a, w, bias, resid=x, out_bf16=False, out_f32=x, tile_cfg=0)
     assert torch.equal(x, f4)
+    b4, _, _ = ops.gemm_nt(a, w, None, tile_cfg=4)   # bf16-only: 256 tiles of 256x384 + the row tail as well
+    b0, _, _ = ops.gemm_nt(a, w, None, tile_cfg=0)
+    assert torch.equal(b4, b0)
 
 
 @pytest.mark.parametrize("N,K", [(3072, 128), (768, 192), (2304, 128)])
