@@ -53,7 +53,6 @@ struct AttnBwdFArgs {
   float scale, scale_log2;
   int causal;
   int nkb, nqt, G, nchains;
-  int dbg;             // timing-only ablations (LC2IS_ATTN_BWD_DBG; results are wrong when set): 1 no flag wait, 2 no acquire, 4 no R traffic
 };
 
 constexpr float LOG2E_F = 1.44269504088896341f;
@@ -304,7 +303,7 @@ __global__ __launch_bounds__(256, (D == 64 && NKT == 1) ? 2 : 1) void attn_bwd_f
 
       int before, last;
       chain_pos(t, before, last);
-      const bool need_sum = before > 0 && !(p.dbg & 4);
+      const bool need_sum = before > 0;
       // the flag of this tile's predecessors: asked for now, looked at after the two halves
       unsigned fv = 0;
       if (need_sum) fv = __hip_atomic_load(flag_of(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -398,7 +397,7 @@ __global__ __launch_bounds__(256, (D == 64 && NKT == 1) ? 2 : 1) void attn_bwd_f
         unsigned* f = flag_of(t);
         unsigned v = __builtin_amdgcn_readfirstlane(fv);
         unsigned spins = 0;
-        while (v < (unsigned)before && !(p.dbg & 1)) {   // (nothing of this wave's is unpublished here: it cannot be part of a cycle)
+        while (v < (unsigned)before) {   // (nothing of this wave's is unpublished here: it cannot be part of a cycle)
           __builtin_amdgcn_s_sleep(2);
           v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
           if ((++spins & 1023u) == 0) {
@@ -472,7 +471,7 @@ __global__ __launch_bounds__(256, (D == 64 && NKT == 1) ? 2 : 1) void attn_bwd_f
               const unsigned hi = pack_bf16x2(dq[i][4 * c + 2] * p.scale, dq[i][4 * c + 3] * p.scale);
               __builtin_amdgcn_raw_buffer_store_b64(i32x2_t{(int)lo, (int)hi}, rsD, base < 0 ? -1 : base + 16 * c, 0, 0);
             }
-          } else if (!(p.dbg & 4)) {
+          } else {
             const __amdgpu_buffer_rsrc_t rsR = make_rsrc(p.R, rbytes);
             const int ro = r_off(t, id);
 #pragma unroll
@@ -690,7 +689,7 @@ extern "C" int lc2is_attention_bwd_fused(const void* Q, int ldq, const void* K, 
   AttnBwdFArgs a{(const bf16_t*)Q, ldq, (const bf16_t*)K, ldk, (const bf16_t*)V, ldv, (const bf16_t*)dO, lddo,
                  (bf16_t*)dQ, lddq, (bf16_t*)dK, lddk, (bf16_t*)dV, lddv, lse2, delta, kbias,
                  (float*)((char*)workspace + f.state_bytes), (unsigned*)workspace, B, H, Sq, Sk, scale, scale * LOG2E_F,
-                 causal, f.nkb, f.nqt, f.G, f.nchains, getenv("LC2IS_ATTN_BWD_DBG") ? atoi(getenv("LC2IS_ATTN_BWD_DBG")) : 0};
+                 causal, f.nkb, f.nqt, f.G, f.nchains};
   switch (D) {
     case 64: return nkt == 2 ? launch_fused<64, 2>(a, stream) : launch_fused<64, 1>(a, stream);
     case 96: return launch_fused<96, 1>(a, stream);
