@@ -247,7 +247,7 @@ __device__ __forceinline__ void gemm_epilogue_lds_act(const GemmNtArgs& p, f32x4
         const int r = it * 8 + srow, m = mrow0 + r;
         const i32x4_t v = *(const i32x4_t*)(patch + r * PITCH + sch * 16);
         if constexpr (RC)
-          __builtin_amdgcn_raw_buffer_store_b128(v, rsY, (m < p.M && col_ok) ? (m * p.ldy + nw + sch * 8) * 2 : OOB, 0, 2);   // nt
+          __builtin_amdgcn_raw_buffer_store_b128(v, rsY, (m < p.M && col_ok) ? (m * p.ldy + nw + sch * 8) * 2 : OOB, 0, 2);   // nt: read again only in the backward pass
         else if (m < p.M && col_ok) __builtin_nontemporal_store(v, (i32x4_t*)(p.aux_out + (size_t)m * p.ldy + nw + sch * 8));
       }
     }
@@ -305,7 +305,7 @@ __device__ __forceinline__ void gemm_epilogue_lds_act(const GemmNtArgs& p, f32x4
         const int r = it * 8 + srow, m = mrow0 + r;
         const i32x4_t v = *(const i32x4_t*)(patch + r * PITCH + sch * 16);
         if constexpr (RC)
-          __builtin_amdgcn_raw_buffer_store_b128(v, rsO, (m < p.M && col_ok) ? (m * p.ldo + nw + sch * 8) * 2 : OOB, 0, 2);   // nt
+          __builtin_amdgcn_raw_buffer_store_b128(v, rsO, (m < p.M && col_ok) ? (m * p.ldo + nw + sch * 8) * 2 : OOB, 0, 0);   // write-back: the next kernel reads it (round 4: +1.5 % of the step against nt, profiles/r04_gemm_store_policy_ab.txt)
         else if (m < p.M && col_ok) __builtin_nontemporal_store(v, (i32x4_t*)(p.out_bf16 + (size_t)m * p.ldo + nw + sch * 8));
       }
     }
@@ -700,7 +700,8 @@ __global__ __launch_bounds__(512) void gemm_nt_w384_kernel(GemmNtArgs p) {
       for (int q = 0; q < 6; ++q) {
         const int row = (q / 3) * 16 + brow[q % 3], col = nwb + bch[q % 3] * 8;
         const i32x4_t v = *(const i32x4_t*)(patchb + row * PITCHB + bch[q % 3] * 16);
-        __builtin_amdgcn_raw_buffer_store_b128(v, rsB, col < p.N ? ((mrow0 + row) * p.ldo + col) * 2 : OOBB, 0, 2);   // nt
+        const int b_off = col < p.N ? ((mrow0 + row) * p.ldo + col) * 2 : OOBB;
+        __builtin_amdgcn_raw_buffer_store_b128(v, rsB, b_off, 0, 0);   // write-back: the next kernel reads it
       }
     }
     return;
@@ -741,7 +742,8 @@ __global__ __launch_bounds__(512) void gemm_nt_w384_kernel(GemmNtArgs p) {
       for (int q = 0; q < 6; ++q) {
         const int row = ((hq + q) / 3) * 8 + frow8[q % 3], col = nw + fch[q % 3] * 4;
         const f32x4_t v = *(const f32x4_t*)(patch + row * PITCH + fch[q % 3] * 16) + __builtin_bit_cast(f32x4_t, rv[q]);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, v), rsO, col < p.N ? ((mrow0 + row) * p.ldf + col) * 4 : OOB, 0, 2);   // nt
+        const int o_off = col < p.N ? ((mrow0 + row) * p.ldf + col) * 4 : OOB;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, v), rsO, o_off, 0, 0);   // write-back: LayerNorm reads the stream next
       }
     }
   }
@@ -1128,7 +1130,8 @@ int launch_w384(const GemmNtArgs& a, hipStream_t stream) {
 
 int launch_rows(const GemmNtArgs& a, hipStream_t stream) {
   if (a.M > 64 || a.N % 4) return LC2IS_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(gemm_nt_rows_kernel<16>, dim3((a.N + 15) / 16, (a.M + 15) / 16), dim3(64), 0, stream, a);
+  if (a.K >= 2048) hipLaunchKernelGGL(gemm_nt_rows_kernel<28>, dim3((a.N + 15) / 16, (a.M + 15) / 16), dim3(64), 0, stream, a);   // long K: 56 loads in flight per wave (the 6-bit vmcnt allows 63)
+  else hipLaunchKernelGGL(gemm_nt_rows_kernel<16>, dim3((a.N + 15) / 16, (a.M + 15) / 16), dim3(64), 0, stream, a);
   return lc2is_check_launch();
 }
 
