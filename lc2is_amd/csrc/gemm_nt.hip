@@ -1263,12 +1263,12 @@ extern "C" int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw
   // cfg 16 (256x384 tiles): N = 768 at M = 128 x 256 is exactly one round instead of 1.5 (LC2IS_GEMM_W384=0: off)
   static const bool use_w384 = !(getenv("LC2IS_GEMM_W384") && atoi(getenv("LC2IS_GEMM_W384")) == 0);
   static const bool use_w384_bf16 = !(getenv("LC2IS_GEMM_W384_BF16") && atoi(getenv("LC2IS_GEMM_W384_BF16")) == 0);
-  if (use_w384 && use_w384_bf16 && w384_bf16_ok(a)) {   // bf16-only, no activation (dqkv, dfc1, dout_proj): take it where it saves >= 15 % of the tile time
+  if (use_w384 && use_w384_bf16 && w384_bf16_ok(a)) {   // bf16-only, no activation (dqkv, dfc1, dout_proj): take it where it saves >= 8 % of the tile time
     const int r = M % 256;
     const bool can_peel = r > 0 && r <= 64 && M > 256;
     const int mm = can_peel ? M - r : M;
     const long t384 = (long)((mm + 255) / 256) * (N / 384), t256 = (long)((mm + 255) / 256) * (N / 256);
-    if ((double)((t384 + 255) / 256) * 1.5 < 0.85 * (double)((t256 + 255) / 256)) {
+    if ((double)((t384 + 255) / 256) * 1.5 < 0.92 * (double)((t256 + 255) / 256)) {   // (qkv, N = 2304: 3 rounds of 384 = 4.5 against 5 tile times: 117 vs 123 us)
       GemmNtArgs main_part = a, tail = a;
       main_part.M = mm;
       int rc = launch_by_cfg(main_part, 16, stream);
