@@ -590,6 +590,50 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_dma_kernel(Gemm
   gemm_epilogue<TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lane);
 }
 
+// ---- ragged-row tail (cfg 17, round 4) ------------------------------------------------------------------------------------------
+// The <= 64 rows that the exact-round plans peel off (B x 1025 tokens: 32 rows) used to go through the 64x64 register-staged kernel:
+// 12 blocks walking K = 3072 in 48 latency-bound steps = 22 us, as much as the 256x384 plan saves.  Here ONE WAVE owns 16 rows x 16
+// columns and the whole K: both operands come straight from global memory in the MFMA fragment layout (a lane's 8 consecutive K
+// elements are 16 contiguous bytes of a row), PD K chunks of 32 in flight, no LDS, no barrier.  Same MFMA, same operand roles and the
+// same sequential order over K as the tile kernels, and their unstaged epilogue: bitwise equal to tile_cfg 4 for every activation.
+// rows_fragment: one such fragment (rows m0.., columns n0..) by the calling wave; ACT < 0: the run-time switch over every epilogue.
+template <int PD, int ACT>
+__device__ __forceinline__ void rows_fragment(const GemmNtArgs& p, int n0, int m0, int lane) {
+  const int frow = lane & 15, g = lane >> 4;
+  constexpr int OOB = 0x7fffffff;
+  const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, (unsigned)p.M * (unsigned)p.lda * 2u);
+  const __amdgpu_buffer_rsrc_t rsW = make_rsrc(p.W, (unsigned)p.N * (unsigned)p.ldw * 2u);
+  const bool n_ok = n0 + frow < p.N;
+  const int a_off = ((m0 + frow) * p.lda + g * 8) * 2;   // rows >= M fall outside num_records: zeros
+  const int w_off = n_ok ? ((n0 + frow) * p.ldw + g * 8) * 2 : OOB;
+  const int kbytes = p.K * 2;
+  bf16x8_t wa[PD], xa[PD];
+#pragma unroll
+  for (int i = 0; i < PD; ++i) {
+    const int kb = i * 64;
+    wa[i] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rsW, kb < kbytes ? w_off + kb : OOB, 0, 0));
+    xa[i] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rsA, kb < kbytes ? a_off + kb : OOB, 0, 0));
+  }
+  f32x4_t acc[1][1] = {{f32x4_t{0.f, 0.f, 0.f, 0.f}}};
+  for (int kb0 = 0; kb0 < kbytes; kb0 += PD * 64) {
+#pragma unroll
+    for (int i = 0; i < PD; ++i) {
+      if (kb0 + i * 64 < kbytes)   // (uniform; chunks past K are never accumulated: the sum stays the tile kernels' sum)
+        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[i], xa[i], acc[0][0], 0, 0, 0);
+      const int kb = kb0 + (i + PD) * 64;
+      wa[i] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rsW, kb < kbytes ? w_off + kb : OOB, 0, 0));
+      xa[i] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rsA, kb < kbytes ? a_off + kb : OOB, 0, 0));
+    }
+  }
+  if constexpr (ACT < 0) gemm_epilogue<1, 1, 16, 16>(p, acc, m0, n0, 0, 0, lane);   // every epilogue of the tile kernels (same arithmetic, unstaged)
+  else gemm_epilogue_act<ACT, 1, 1, 16, 16>(p, acc, m0, n0, 0, 0, lane);
+}
+
+template <int PD>
+__global__ __launch_bounds__(64) void gemm_nt_rows_kernel(GemmNtArgs p) {
+  rows_fragment<PD, -1>(p, blockIdx.x * 16, blockIdx.y * 16, threadIdx.x);
+}
+
 // ---- 256x384 tile for the N = 768 problems (cfg 16, round 4) -------------------------------------------------------------------
 // The residual-stream GEMMs of the ViT-B tower (out-proj, fc2 and the dgrads into the fp32 stream: N = 768, M = B x 1025) are 3
 // column tiles of 256: 384 tiles after the ragged-row peel = 1.5 rounds of the 256 CUs.  With 384-wide tiles they are 2 x 128 =
@@ -704,8 +748,7 @@ __global__ __launch_bounds__(512) void gemm_nt_w384_kernel(GemmNtArgs p) {
         __builtin_amdgcn_raw_buffer_store_b128(v, rsB, b_off, 0, 0);   // write-back: the next kernel reads it
       }
     }
-    return;
-  }
+  } else {
   // ---- epilogue: out = acc + bias (+ fp32 residual), 32 rows x 96 columns of the wave at a time through its LDS patch ----
   constexpr int PITCH = WN * 4 + 16;   // 400 B: 16 lanes of a ds_write_b128 group land on 16 distinct bank quads
   char* patch = smem + wid * (32 * PITCH);
@@ -747,44 +790,15 @@ __global__ __launch_bounds__(512) void gemm_nt_w384_kernel(GemmNtArgs p) {
       }
     }
   }
-}
-
-// ---- ragged-row tail (cfg 17, round 4) ------------------------------------------------------------------------------------------
-// The <= 64 rows that the exact-round plans peel off (B x 1025 tokens: 32 rows) used to go through the 64x64 register-staged kernel:
-// 12 blocks walking K = 3072 in 48 latency-bound steps = 22 us, as much as the 256x384 plan saves.  Here ONE WAVE owns 16 rows x 16
-// columns and the whole K: both operands come straight from global memory in the MFMA fragment layout (a lane's 8 consecutive K
-// elements are 16 contiguous bytes of a row), PD K chunks of 32 in flight, no LDS, no barrier.  Same MFMA, same operand roles and the
-// same sequential order over K as the tile kernels, and their unstaged epilogue: bitwise equal to tile_cfg 4 for every activation.
-template <int PD>
-__global__ __launch_bounds__(64) void gemm_nt_rows_kernel(GemmNtArgs p) {
-  const int lane = threadIdx.x, frow = lane & 15, g = lane >> 4;
-  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
-  constexpr int OOB = 0x7fffffff;
-  const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, (unsigned)p.M * (unsigned)p.lda * 2u);
-  const __amdgpu_buffer_rsrc_t rsW = make_rsrc(p.W, (unsigned)p.N * (unsigned)p.ldw * 2u);
-  const bool n_ok = n0 + frow < p.N;
-  const int a_off = ((m0 + frow) * p.lda + g * 8) * 2;   // rows >= M fall outside num_records: zeros
-  const int w_off = n_ok ? ((n0 + frow) * p.ldw + g * 8) * 2 : OOB;
-  const int kbytes = p.K * 2;
-  bf16x8_t wa[PD], xa[PD];
-#pragma unroll
-  for (int i = 0; i < PD; ++i) {
-    const int kb = i * 64;
-    wa[i] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rsW, kb < kbytes ? w_off + kb : OOB, 0, 0));
-    xa[i] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rsA, kb < kbytes ? a_off + kb : OOB, 0, 0));
   }
-  f32x4_t acc[1][1] = {{f32x4_t{0.f, 0.f, 0.f, 0.f}}};
-  for (int kb0 = 0; kb0 < kbytes; kb0 += PD * 64) {
-#pragma unroll
-    for (int i = 0; i < PD; ++i) {
-      if (kb0 + i * 64 < kbytes)   // (uniform; chunks past K are never accumulated: the sum stays the tile kernels' sum)
-        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[i], xa[i], acc[0][0], 0, 0, 0);
-      const int kb = kb0 + (i + PD) * 64;
-      wa[i] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rsW, kb < kbytes ? w_off + kb : OOB, 0, 0));
-      xa[i] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rsA, kb < kbytes ? a_off + kb : OOB, 0, 0));
-    }
+  // ---- folded ragged rows: fragment jobs wid * gridDim.x + blockIdx.x, ... (wave 0 of every block first) ----
+  if (p.tail_rows > 0) {
+    GemmNtArgs q = p;
+    q.M = p.M + p.tail_rows;
+    const int nfn = p.N / 16, njobs = nfn * ((p.tail_rows + 15) / 16);
+    for (int job = wid * (int)gridDim.x + (int)blockIdx.x; job < njobs; job += 8 * (int)gridDim.x)
+      rows_fragment<16, LC2IS_ACT_NONE>(q, (job % nfn) * 16, p.M + (job / nfn) * 16, lane);
   }
-  gemm_epilogue<1, 1, 16, 16>(p, acc, m0, n0, 0, 0, lane);   // every epilogue of the tile kernels (same arithmetic, unstaged)
 }
 
 // ---- persistent form with counted waits across the tile seam (cfg 13) ------------------------------------------------------
@@ -1051,6 +1065,16 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmNtArgs p, int ntile
     issued += nstores;
     if (!more) break;
   }
+  // ---- folded ragged rows (see gemm_nt_w384_kernel): fragment jobs after the block's last tile (not in the derivative instantiation:
+  // with its aux_in epilogue the section costs the 256-register kernel 12 bytes of scratch; dfc2 keeps its separate tail launch) ----
+  if constexpr (ACT != LC2IS_ACT_DQUICK_GELU)
+  if (p.tail_rows > 0) {
+    GemmNtArgs q = p;
+    q.M = p.M + p.tail_rows;
+    const int nfn = p.N / 16, njobs = nfn * ((p.tail_rows + 15) / 16);
+    for (int job = wid * (int)gridDim.x + (int)blockIdx.x; job < njobs; job += 8 * (int)gridDim.x)
+      rows_fragment<16, ACT>(q, (job % nfn) * 16, p.M + (job / nfn) * 16, lane0);
+  }
 }
 
 template <int ACT>
@@ -1252,6 +1276,8 @@ extern "C" int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw
   if (cfg != 0) return launch_by_cfg(a, cfg, stream);
   // ragged-row tails (<= 64 rows) of the exact-round plans: the one-wave-per-fragment kernel (cfg 17); LC2IS_GEMM_ROWS_TAIL=0: 64x64 tiles
   static const int tail_cfg = (getenv("LC2IS_GEMM_ROWS_TAIL") && atoi(getenv("LC2IS_GEMM_ROWS_TAIL")) == 0) ? 3 : 17;
+  // ... and behind a 256x384 launch they are folded into it (fragment jobs after each block's own tile); LC2IS_GEMM_TAIL_FOLD=0: separate launch
+  static const bool fold_tail = tail_cfg == 17 && !(getenv("LC2IS_GEMM_TAIL_FOLD") && atoi(getenv("LC2IS_GEMM_TAIL_FOLD")) == 0);
   const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
   static const long cfg6_min = getenv("LC2IS_GEMM_CFG6_MIN") ? atol(getenv("LC2IS_GEMM_CFG6_MIN")) : 128;   // (512 and the register-staged 128x128 kernel below it measured 0.8 % slower on config 5)
   if (!(tiles128 >= 1024 && N % 256 == 0)) {
@@ -1271,8 +1297,9 @@ extern "C" int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw
     if ((double)((t384 + 255) / 256) * 1.5 < 0.92 * (double)((t256 + 255) / 256)) {   // (qkv, N = 2304: 3 rounds of 384 = 4.5 against 5 tile times: 117 vs 123 us)
       GemmNtArgs main_part = a, tail = a;
       main_part.M = mm;
+      if (fold_tail) main_part.tail_rows = M - mm;   // the ragged rows ride in the same launch (rows M .. follow in the same buffers)
       int rc = launch_by_cfg(main_part, 16, stream);
-      if (rc || mm == M) return rc;
+      if (rc || mm == M || fold_tail) return rc;
       tail.M = M - mm;
       tail.A = a.A + (size_t)mm * lda;
       tail.out_bf16 = a.out_bf16 + (size_t)mm * ldo;
@@ -1295,8 +1322,9 @@ extern "C" int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw
     if (peel && r > 0 && r <= 64 && M > 256 && (tiles_main + 255) / 256 < (tiles_all + 255) / 256) {
       GemmNtArgs main_part = a, tail = a;
       main_part.M = M - r;
+      if (fold_tail && pcfg == 15 && N % 16 == 0 && act != LC2IS_ACT_DQUICK_GELU) main_part.tail_rows = r;
       int rc = launch_by_cfg(main_part, pcfg, stream);
-      if (rc) return rc;
+      if (rc || main_part.tail_rows) return rc;
       const size_t m0 = (size_t)(M - r);
       tail.M = r;
       tail.A = a.A + m0 * lda;
@@ -1328,8 +1356,9 @@ extern "C" int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw
   if (best_main == M) return launch_by_cfg(a, best_cfg, stream);
   GemmNtArgs main_part = a, tail = a;
   main_part.M = best_main;
+  if (best_cfg == 16 && fold_tail) main_part.tail_rows = M - best_main;
   int rc = launch_by_cfg(main_part, best_cfg, stream);
-  if (rc) return rc;
+  if (rc || main_part.tail_rows) return rc;
   const size_t m0 = (size_t)best_main;
   tail.M = M - best_main;
   tail.A = a.A + m0 * lda;

@@ -20,6 +20,9 @@ struct GemmNtArgs {
                    // 2 (host side only, cleared before the launch): fp32-only output through LDS (F32EPI instantiations)
   // strided-batched form (gemm_nt_kernel only; blockIdx.y = batch): element strides between consecutive problems
   long bsA, bsW, bsOb, bsOf;
+  // ragged rows folded into a large-tile launch (256x384 kernels): rows M .. M + tail_rows - 1 of the same A / output buffers are
+  // computed by the blocks' waves after their own tile, one 16 x 16 fragment each (the rows kernel's algorithm, no second launch)
+  int tail_rows;
 };
 
 __device__ __forceinline__ float sigmoidf_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }  // v_exp + v_rcp

@@ -242,6 +242,31 @@ def test_gemm_nt_auto_plan_picks_exact_round_and_matches(dev):
     assert torch.equal(b4, b0)
 
 
+@pytest.mark.parametrize("N,K", [(3072, 128), (3072, 768), (2304, 192)])
+def test_gemm_nt_auto_plan_persistent_with_folded_tail(dev, N, K):
+    """M = 64*256 + 32 rows with bf16 outputs: the automatic plan is the persistent ping-pong kernel (or 256x384 tiles for N = 2304)
+    over the whole tiles with the 32 ragged rows FOLDED into the same launch (fragment jobs after each block's last tile; the
+    derivative epilogue keeps a separate tail launch) — bitwise equal to the single-launch 256x256 plan for the three epilogues of
+    the tower: bias, quick_gelu + saved pre-activation, x quick_gelu'(saved)."""
+    from lc2is_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(N + K)
+    M = 64 * 256 + 32
+    a = _bf(torch.randn(M, K, generator=g)).to(dev)
+    w = _bf(torch.randn(N, K, generator=g) * 0.1).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    saved = _bf(torch.randn(M, N, generator=g)).to(dev)
+    for rep in range(2):
+        o4, _, _ = ops.gemm_nt(a, w, bias, tile_cfg=4)
+        o0, _, _ = ops.gemm_nt(a, w, bias, tile_cfg=0)
+        assert torch.equal(o4, o0)
+        o4, _, z4 = ops.gemm_nt(a, w, bias, act=ops.ACT_QUICK_GELU, aux_out=True, tile_cfg=4)
+        o0, _, z0 = ops.gemm_nt(a, w, bias, act=ops.ACT_QUICK_GELU, aux_out=True, tile_cfg=0)
+        assert torch.equal(o4, o0) and torch.equal(z4, z0)
+        d4, _, _ = ops.gemm_nt(a, w, None, act=ops.ACT_DQUICK_GELU, aux_in=saved, tile_cfg=4)
+        d0, _, _ = ops.gemm_nt(a, w, None, act=ops.ACT_DQUICK_GELU, aux_in=saved, tile_cfg=0)
+        assert torch.equal(d4, d0)
+
+
 @pytest.mark.parametrize("N,K", [(3072, 128), (768, 192), (2304, 128)])
 def test_gemm_nt_auto_plan_ragged_rows(dev, N, K):
     """M = 64*256 + 32 rows (the B x 1025-token shape): the automatic plan peels the ragged rows into a small-tile
