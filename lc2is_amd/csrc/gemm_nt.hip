@@ -1080,8 +1080,12 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmNtArgs p, int ntile
 template <int ACT>
 int launch_pp_act(const GemmNtArgs& a, hipStream_t stream) {
   constexpr int LDS = (256 + 256) * 128 + 8 * 64 * 144;
-  if (hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
-    return LC2IS_ERR_LAUNCH;
+  static DevOnce attr_set;
+  if (attr_set.need()) {
+    if (hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+      return LC2IS_ERR_LAUNCH;
+    attr_set.done();
+  }
   const int ntiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
   const int grid = ntiles < 256 ? ntiles : 256;
   hipLaunchKernelGGL(gemm_nt_pp_kernel<ACT>, dim3(grid), dim3(512), LDS, stream, a, ntiles);
