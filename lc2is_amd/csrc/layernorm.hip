@@ -16,6 +16,9 @@ namespace {
 #endif
 constexpr int LN_MAXV = 8;  // float4 per lane -> C <= 2048 (kernels are instantiated for NV = 1,2,3,4,6,8)
 
+// A wave walks rows blockIdx.x * 4 + wave, + 4 * gridDim.x, ... : gamma / beta are read once per wave instead of once per row and the
+// next row's x is requested before the current row's reductions (round 4; worth 0.2 % of the step: 1018 vs 1016 img/s against one
+// row per wave).  The arithmetic of a row is unchanged (bitwise the same outputs).
 template <int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int ldx,
                                                       const float* __restrict__ gamma,
@@ -23,56 +26,71 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                       float* yf, int ldyf, float* mean_out, float* rstd_out,
                                                       int M, int C, float eps) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
   const int C4 = C >> 2;
-  const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * ldx);
-  float4 v[NV];
-  float s = 0.f;
+  float4 gm[NV], bt[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c4 = lane + 64 * i;
-    if (c4 < C4) {
-      v[i] = xr[c4];
-      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-    } else {
-      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    gm[i] = (c4 < C4) ? reinterpret_cast<const float4*>(gamma)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    bt[i] = (beta && c4 < C4) ? reinterpret_cast<const float4*>(beta)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int stride = gridDim.x * 4;
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  auto load_row = [&](int r, float4 (&dst)[NV]) __attribute__((always_inline)) {
+    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)r * ldx);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c4 = lane + 64 * i;
+      dst[i] = (c4 < C4) ? xr[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-  }
-  const float mean = wave_sum(s) / (float)C;
-  float q = 0.f;
+  };
+  float4 v[NV], nx[NV];
+  load_row(row, v);
+  for (; row < M; row += stride) {
+    const bool more = row + stride < M;
+    if (more) load_row(row + stride, nx);
+    float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c4 = lane + 64 * i;
-    if (c4 < C4) {
-      const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
-      q += (a * a + b * b) + (c * c + d * d);
+    for (int i = 0; i < NV; ++i) {
+      const int c4 = lane + 64 * i;
+      if (c4 < C4) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
-  }
-  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
-  if (lane == 0) {
-    if (mean_out) mean_out[row] = mean;
-    if (rstd_out) rstd_out[row] = rstd;
-  }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c4 = lane + 64 * i;
-    if (c4 < C4) {
-      const float4 gm = reinterpret_cast<const float4*>(gamma)[c4];
-      float4 o;
-      o.x = (v[i].x - mean) * rstd * gm.x;
-      o.y = (v[i].y - mean) * rstd * gm.y;
-      o.z = (v[i].z - mean) * rstd * gm.z;
-      o.w = (v[i].w - mean) * rstd * gm.w;
-      if (beta) {
-        const float4 bt = reinterpret_cast<const float4*>(beta)[c4];
-        o.x += bt.x; o.y += bt.y; o.z += bt.z; o.w += bt.w;
+    for (int i = 0; i < NV; ++i) {
+      const int c4 = lane + 64 * i;
+      if (c4 < C4) {
+        const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+        q += (a * a + b * b) + (c * c + d * d);
       }
-      if (y) {
-        uint2 pk = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
-        *reinterpret_cast<uint2*>(y + (size_t)row * ldy + 4 * c4) = pk;
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    if (lane == 0) {
+      if (mean_out) mean_out[row] = mean;
+      if (rstd_out) rstd_out[row] = rstd;
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c4 = lane + 64 * i;
+      if (c4 < C4) {
+        float4 o;
+        o.x = (v[i].x - mean) * rstd * gm[i].x;
+        o.y = (v[i].y - mean) * rstd * gm[i].y;
+        o.z = (v[i].z - mean) * rstd * gm[i].z;
+        o.w = (v[i].w - mean) * rstd * gm[i].w;
+        if (beta) { o.x += bt[i].x; o.y += bt[i].y; o.z += bt[i].z; o.w += bt[i].w; }
+        if (y) {
+          uint2 pk = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
+          *reinterpret_cast<uint2*>(y + (size_t)row * ldy + 4 * c4) = pk;
+        }
+        if (yf) *reinterpret_cast<float4*>(yf + (size_t)row * ldyf + 4 * c4) = o;
       }
-      if (yf) *reinterpret_cast<float4*>(yf + (size_t)row * ldyf + 4 * c4) = o;
+    }
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) v[i] = nx[i];
     }
   }
 }
@@ -196,6 +214,13 @@ inline int ln_bwd_blocks(int M, int C) {
 
 }  // namespace
 
+// rows are walked by at most 256 CUs x 8 blocks of four waves (LC2IS_LN_FWD_BLOCKS overrides the cap: A/B)
+static int ln_fwd_blocks(int M) {
+  static const int cap = getenv("LC2IS_LN_FWD_BLOCKS") ? atoi(getenv("LC2IS_LN_FWD_BLOCKS")) : 2048;
+  const int need = (M + 3) / 4;
+  return need < cap ? need : (cap > 0 ? cap : need);
+}
+
 extern "C" int lc2is_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta,
                                    void* y_bf16, int ldy, float* y_f32, int ldyf, float* mean, float* rstd,
                                    int M, int C, float eps, lc2is_stream_t stream_) {
@@ -205,7 +230,7 @@ extern "C" int lc2is_layernorm_fwd(const float* x, int ldx, const float* gamma, 
   if (ldx < C || ldx % 4 || (y_bf16 && (ldy < C || ldy % 4)) || (y_f32 && (ldyf < C || ldyf % 4)))
     return LC2IS_ERR_SHAPE;
 #define LN_FWD(NV_)                                                                                  \
-  hipLaunchKernelGGL(ln_fwd_kernel<NV_>, dim3((M + 3) / 4), dim3(256), 0, stream, x, ldx, gamma, beta, \
+  hipLaunchKernelGGL(ln_fwd_kernel<NV_>, dim3(ln_fwd_blocks(M)), dim3(256), 0, stream, x, ldx, gamma, beta, \
                      (bf16_t*)y_bf16, ldy, y_f32, ldyf, mean, rstd, M, C, eps)
   const int nv = (C / 4 + 63) / 64;
   if (nv <= 1) LN_FWD(1); else if (nv == 2) LN_FWD(2); else if (nv == 3) LN_FWD(3);
