@@ -57,7 +57,12 @@ const char* lc2is_version(void);
  * act: QUICK_GELU/RELU apply after bias and (if aux_out) store the pre-activation as bf16;
  *      DQUICK_GELU/DRELU multiply by the activation derivative at aux_in (saved pre-activation /
  *      saved relu output) — used by the dgrad of fc1 / linear1.
- * Either or both of out_bf16 / out_f32 may be given.  tile_cfg 0 = auto.
+ * Either or both of out_bf16 / out_f32 may be given.  tile_cfg 0 = auto (the plan: exact rounds of 256x256 or 256x384 tiles over
+ * the chip's 256 CUs, persistent form for bf16 outputs, the <= 64 ragged rows of B x 1025-token inputs computed inside the same
+ * launch); a non-zero tile_cfg forces one kernel for tests and A/B (1-3 register-staged 128x128 / 256x128 / 64x64, 4 / 6 LDS-DMA
+ * 256x256 / 128x128, 13 / 15 persistent 256x256, 16 = 256x384 [N % 384 == 0, no activation, fp32-only or bf16-only output], 17 = row
+ * kernel for M <= 64) and returns LC2IS_ERR_UNSUPPORTED where that kernel does not take the problem.  Every plan gives bitwise the
+ * same result as tile_cfg 4.
  * replaces: nn.Linear.forward at hf:CLIPAttention.forward (q/k/v/out_proj), hf:CLIPMLP.forward,
  *   torch:nn/functional.py multi_head_attention_forward in/out projections, DecoderLayer linear1/2
  *   (model/decoder.py:9-21), TextToPatch.forward (model/text_patch.py:14-19),
