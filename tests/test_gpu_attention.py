@@ -190,3 +190,18 @@ def test_attention_bwd_fused_reproducible_and_vs_two_launch(dev, B, H, Sq, Sk, D
     for name, a, b_ in zip(("dq", "dk", "dv"), runs[0], ref):
         rel = ((a.double() - b_.double()).norm() / b_.double().norm()).item()
         assert rel < 6e-3, (name, rel)   # both round fp32 sums to bf16 once; dS / P are rounded to bf16 identically
+
+
+def test_attention_fwd_64_queries_per_wave_variant():
+    """The NQ = 2 instantiation of attn_fwd_kernel (64 queries per wave, 256 per block; opt-in by LC2IS_ATTN_FWD_NQ=2, read once per
+    process — hence a child process): every forward case of this file, the spiked-score and the very-negative-first-key cases run
+    under it against the same fp32 references.  One child, started once (the GPU box allows few processes on the card)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, LC2IS_ATTN_FWD_NQ="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "test_attention_fwd and not 64_queries or very_negative"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
