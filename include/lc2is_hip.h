@@ -52,6 +52,14 @@ typedef struct {
 /* ABI / build identification: returns a static string "lc2is_hip <abi> gfx950". Host memory. */
 const char* lc2is_version(void);
 
+/* Compute units the GEMM tile planners may count on (0 = all 256, the default).  The large-tile kernels run one block per CU and
+ * their plans are whole rounds of the CUs; a CU held by another queue's kernel for the duration (RCCL's channels while gradients
+ * are reduced under the backward pass) would turn "exactly one round" into two.  With a budget n the persistent kernels launch n
+ * blocks and every round count is taken over n CUs.  Process-wide; results do not depend on it (every plan is bitwise equal).
+ * replaces: nothing in the reference (torch DDP leaves this to the vendor GEMM library's heuristics). */
+int lc2is_set_cu_budget(int ncu);
+int lc2is_get_cu_budget(void);
+
 /* ---- dense layers ------------------------------------------------------------------------------
  * out[M,N] = epi(A[M,K] · W[N,K]^T + bias[N]) (+ resid[M,N]); K % 64 == 0, N % 4 == 0.
  * act: QUICK_GELU/RELU apply after bias and (if aux_out) store the pre-activation as bf16;

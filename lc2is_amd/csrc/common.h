@@ -198,6 +198,12 @@ __global__ __launch_bounds__(1024) void partials_reduce_kernel(const float* __re
 
 // "done once PER DEVICE": hipFuncSetAttribute(MaxDynamicSharedMemorySize) belongs to a function ON a device, so a process that
 // drives a second GPU must set it there too (a per-process flag let such a launch fail with ~78 KB of dynamic LDS requested)
+// Compute units the tile planners may count on (lc2is_set_cu_budget; 0 = all 256): every large-tile kernel takes a whole CU per block,
+// so a CU held by another queue's kernel (RCCL's channels under data parallelism) turns "exactly one round of tiles" into two.
+extern "C" int lc2is_get_cu_budget(void);
+static inline int lc2is_ncu() { const int b = lc2is_get_cu_budget(); return b > 0 && b < 256 ? b : 256; }
+static inline long lc2is_rounds(long blocks) { const int n = lc2is_ncu(); return (blocks + n - 1) / n; }
+
 static inline int lc2is_cur_dev() {
   int d = 0;
   (void)hipGetDevice(&d);

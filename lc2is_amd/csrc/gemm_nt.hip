@@ -1087,7 +1087,7 @@ int launch_pp_act(const GemmNtArgs& a, hipStream_t stream) {
     attr_set.done();
   }
   const int ntiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
-  const int grid = ntiles < 256 ? ntiles : 256;
+  const int grid = ntiles < lc2is_ncu() ? ntiles : lc2is_ncu();   // one block per CU of the budget (common.h)
   hipLaunchKernelGGL(gemm_nt_pp_kernel<ACT>, dim3(grid), dim3(512), LDS, stream, a, ntiles);
   return lc2is_check_launch();
 }
@@ -1174,7 +1174,7 @@ int launch_persist2_act(const GemmNtArgs& a, hipStream_t stream) {
     attr_set.done();
   }
   const int ntiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
-  const int grid = ntiles < 256 ? ntiles : 256;
+  const int grid = ntiles < lc2is_ncu() ? ntiles : lc2is_ncu();   // one block per CU of the budget (common.h)
   hipLaunchKernelGGL(gemm_nt_persist2_kernel<ACT>, dim3(grid), dim3(512), LDS, stream, a, ntiles);
   return lc2is_check_launch();
 }
@@ -1298,7 +1298,7 @@ extern "C" int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw
     const bool can_peel = r > 0 && r <= 64 && M > 256;
     const int mm = can_peel ? M - r : M;
     const long t384 = (long)((mm + 255) / 256) * (N / 384), t256 = (long)((mm + 255) / 256) * (N / 256);
-    if ((double)((t384 + 255) / 256) * 1.5 < 0.92 * (double)((t256 + 255) / 256)) {   // (qkv, N = 2304: 3 rounds of 384 = 4.5 against 5 tile times: 117 vs 123 us)
+    if ((double)lc2is_rounds(t384) * 1.5 < 0.92 * (double)lc2is_rounds(t256)) {   // (qkv, N = 2304: 3 rounds of 384 = 4.5 against 5 tile times: 117 vs 123 us)
       GemmNtArgs main_part = a, tail = a;
       main_part.M = mm;
       if (fold_tail) main_part.tail_rows = M - mm;   // the ragged rows ride in the same launch (rows M .. follow in the same buffers)
@@ -1323,7 +1323,7 @@ extern "C" int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw
     static const int pcfg = (getenv("LC2IS_GEMM_PP") && atoi(getenv("LC2IS_GEMM_PP")) == 0) ? 13 : 15;   // cfg 15 = the wave groups in ping-pong (round 4: 966 -> 975 img/s); LC2IS_GEMM_PP=0: cfg 13
     const int r = M % 256;
     const long tiles_all = (long)((M + 255) / 256) * (N / 256), tiles_main = (long)(M / 256) * (N / 256);
-    if (peel && r > 0 && r <= 64 && M > 256 && (tiles_main + 255) / 256 < (tiles_all + 255) / 256) {
+    if (peel && r > 0 && r <= 64 && M > 256 && lc2is_rounds(tiles_main) < lc2is_rounds(tiles_all)) {
       GemmNtArgs main_part = a, tail = a;
       main_part.M = M - r;
       if (fold_tail && pcfg == 15 && N % 16 == 0 && act != LC2IS_ACT_DQUICK_GELU) main_part.tail_rows = r;
@@ -1352,7 +1352,7 @@ extern "C" int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw
       if (split && (r == 0 || r > 64 || M <= bm)) continue;
       const int mm = split ? M - r : M;
       const long tiles = (long)((mm + bm - 1) / bm) * (N / bn);
-      double cost = (double)((tiles + 255) / 256) * bm * bn;
+      double cost = (double)lc2is_rounds(tiles) * bm * bn;
       if (split) cost += 65536.0 * 0.3 * 768.0 / K;                                      // ~8 us for the extra launch
       if (split) cost *= 1.03;                                                            // prefer the plain plan on near-ties
       if (cost < best_cost) { best_cost = cost; best_cfg = c; best_main = mm; }

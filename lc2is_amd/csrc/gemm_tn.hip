@@ -42,7 +42,7 @@ inline TnPlan tn_plan(int M, int N, int K) {
   p.big = 0;
   if (N % 256 == 0 && K % 256 == 0 && tn_forced_cfg() != 1) {
     const int ntn = N / 256, ntk = K / 256, tiles = ntn * ntk;
-    int splits = (256 + tiles / 2) / tiles;
+    int splits = (lc2is_ncu() + tiles / 2) / tiles;   // about one block per CU of the budget (common.h)
     const int max_splits = (M + 511) / 512;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -725,13 +725,14 @@ inline void tg_plan(const lc2is_tn_problem* pr, int n, TgPlan& pl) {
   double best_t = 1e300;
   for (int sp = 1; sp <= max_splits; ++sp) {
     const long blocks = tiles * sp;
-    const double rounds = (double)((blocks + 255) / 256);
+    const double rounds = (double)lc2is_rounds(blocks);
     const double t = rounds * ((max_steps + sp - 1) / sp + 13.0) + (sp > 1 ? sp * wbytes * slab_unit : 0.0);
     if (t < best_t) { best_t = t; best = sp; }
   }
   for (int i = 0; i < n; ++i) { pl.splits[i] = best; pl.order[i] = i; }
-  const int rem = (int)(tiles % 256);
-  if (n > 1 && tiles > 256 && rem != 0 && max_splits >= 2) {
+  const int ncu = lc2is_ncu();   // (256, or the budget set while another queue's kernels hold CUs: common.h)
+  const int rem = (int)(tiles % ncu);
+  if (n > 1 && tiles > ncu && rem != 0 && max_splits >= 2) {
     bool in_tail[TG_TBL_MAX] = {};
     int ts = 0;
     double tail_bytes = 0;
@@ -744,10 +745,10 @@ inline void tg_plan(const lc2is_tn_problem* pr, int n, TgPlan& pl) {
       ts += ptiles[pick];
       tail_bytes += 4.0 * pr[pick].N * pr[pick].K;
     }
-    int sp = ts > 0 ? 256 / ts : 0;
+    int sp = ts > 0 ? ncu / ts : 0;
     if (sp > max_splits) sp = max_splits;
     if (ts >= rem && sp >= 2) {
-      const double rounds = (double)((tiles - ts + 255) / 256);
+      const double rounds = (double)lc2is_rounds(tiles - ts);
       const double t = rounds * (max_steps + 13.0) + ((max_steps + sp - 1) / sp + 13.0) + sp * tail_bytes * slab_unit;
       if (t < best_t) {
         int k = 0;

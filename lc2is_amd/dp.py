@@ -35,6 +35,12 @@ class GradReducer:
         self.bucket_elems = bucket_elems     # layers are reduced in buckets of >= this many elements (48 MB fp32): xGMI
         self._bucket = {}                    # rings are per-link bound and want large messages, not one per layer
         self._early = {}
+        # CUs left to RCCL's channel kernels while collectives are in flight (LC2IS_DP_CU_RESERVE, default 0 = plan on all 256): every
+        # large-tile GEMM block takes a whole CU, so a CU held by a collective turns "one round of tiles" into two.  Set from the
+        # first all_reduce of a step to finish_step (lc2is_set_cu_budget; the plans are bitwise equal, only their shape changes).
+        import os
+        self.cu_reserve = max(0, min(128, int(os.environ.get("LC2IS_DP_CU_RESERVE", "0"))))
+        self._budget_on = False
 
     # -- wiring ------------------------------------------------------------------------------------------------
     def attach(self, model, arena) -> None:
@@ -124,7 +130,15 @@ class GradReducer:
         self._zero_missing(params)
         self.reduce_ranges(self._flat, self._subtract(ranges, self._early.get(key, [])))
 
+    def _set_budget(self, on: bool) -> None:
+        if self.cu_reserve and on != self._budget_on and self._flat is not None and self._flat.is_cuda:
+            from . import ops
+            ops.set_cu_budget(256 - self.cu_reserve if on else 0)
+            self._budget_on = on
+
     def reduce_ranges(self, flat: torch.Tensor, ranges) -> None:
+        if ranges:
+            self._set_budget(True)
         for lo, hi in ranges:
             for a in range(lo, hi, self.max_chunk):
                 b = min(a + self.max_chunk, hi)
@@ -140,6 +154,7 @@ class GradReducer:
         for w in self._pending:
             w.wait()
         self._pending.clear()
+        self._set_budget(False)
 
     def broadcast_params(self, flat_params: torch.Tensor, src: int = 0) -> None:
         dist.broadcast(flat_params, src=src, group=self.group)

@@ -47,6 +47,8 @@ _ARGTYPES = {
     "lc2is_dropout_rows_bf16": [_P, _I, _P, _I, _I, _I, _F, _U64, _P],
     "lc2is_dropout_mask": [_P, _L, _I, _F, _U64, _P],
     "lc2is_shadow_refresh": [_P, _I, _I, _P],
+    "lc2is_set_cu_budget": [_I],
+    "lc2is_get_cu_budget": [],
     "lc2is_cast_f32_bf16": [_P, _I, _P, _I, _I, _I, _P],
     "lc2is_transpose_bf16": [_P, _I, _P, _I, _I, _I, _P],
     "lc2is_patchify": [_P, _P, _I, _I, _I, _I, _I, _P],
@@ -966,3 +968,12 @@ def crop_lut(src: torch.Tensor, top: int, left: int, S: int, *, lut_f32: torch.T
                                _ptr(lut_i64), _ptr(out_i64 if lut_i64 is not None else None), _stream())
     _lib.check(rc, f"crop_lut {H}x{W} crop {S}@({top},{left})")
     return out_f32, out_i64
+
+
+def set_cu_budget(ncu: int) -> None:
+    """Compute units the GEMM tile planners may count on (0 = all 256): include/lc2is_hip.h lc2is_set_cu_budget."""
+    _lib.check(_fn("lc2is_set_cu_budget")(int(ncu)), "set_cu_budget")
+
+
+def get_cu_budget() -> int:
+    return int(_fn("lc2is_get_cu_budget")())

@@ -540,3 +540,43 @@ def test_gemm_tn_grouped_whole_tower_table_and_tail_split(dev):
         assert torch.equal(a[2], b[2]) and (a[3] is None or torch.equal(a[3], b[3]))   # bitwise reproducible
     with pytest.raises(RuntimeError):
         ops.gemm_tn_grouped(probs * 3)      # 177 problems > LC2IS_TN_GROUP_MAX
+
+
+def test_cu_budget_changes_plans_not_results(dev):
+    """lc2is_set_cu_budget(n): the tile planners count rounds over n CUs (the persistent kernels launch n blocks, the exact-round
+    256x384 plan is dropped where it no longer saves a round, the grouped weight-gradient plan fills rounds of n) — what the
+    data-parallel reducer sets while RCCL's channels hold CUs.  Every NT plan is bitwise equal, so those results must not move; the
+    weight gradient's M-split follows its plan, so it may move by fp32 rounding."""
+    from lc2is_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(11)
+    M, N, K = 32800, 768, 256
+    a = _bf(torch.randn(M, K, generator=g)).to(dev)
+    w = _bf(torch.randn(N, K, generator=g) * 0.1).to(dev)
+    w3 = _bf(torch.randn(3072, K, generator=g) * 0.1).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    resid = torch.randn(M, N, generator=g).to(dev)
+    dy = _bf(torch.randn(M, N, generator=g)).to(dev)
+    assert ops.get_cu_budget() == 0
+
+    def run():
+        _, f, _ = ops.gemm_nt(a, w, bias, resid=resid, out_bf16=False, out_f32=True)
+        b16, _, _ = ops.gemm_nt(a, w, bias)
+        z, _, zz = ops.gemm_nt(a, w3, None, act=ops.ACT_QUICK_GELU, aux_out=True)
+        db = torch.empty(N, device=dev)
+        dw = ops.gemm_tn(dy, a, db=db)
+        return f, b16, z, zz, dw, db
+
+    ref = run()
+    try:
+        for budget in (240, 200, 256):
+            ops.set_cu_budget(budget)
+            assert ops.get_cu_budget() == budget
+            out = run()
+            for x, y in zip(out[:4], ref[:4]):
+                assert torch.equal(x, y)
+            for x, y in zip(out[4:], ref[4:]):   # the weight gradient's M-split (hence its fp32 summation order) follows the plan
+                assert _rel(x, y) < 1e-5
+    finally:
+        ops.set_cu_budget(0)
+    with pytest.raises(Exception):
+        ops.set_cu_budget(300)
