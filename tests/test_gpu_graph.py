@@ -52,9 +52,9 @@ def test_graph_replay_matches_eager(dev):
         losses_e.append(ts_e.step(inp, lab).item())
         losses_g.append(run(inp, lab).item())
     torch.cuda.synchronize()
-    assert losses_e == pytest.approx(losses_g, abs=1e-5), (losses_e, losses_g)
+    assert losses_e == pytest.approx(losses_g, rel=2e-6, abs=1e-5), (losses_e, losses_g)   # (the head scatters with fp32 atomics: the last bit of a loss of 2e4 is 2e-3)
     d = (ts_e.arena.flat - ts_g.arena.flat).abs().max().item()
-    assert d < 1e-6, d
+    assert d < 1e-6 * max(1.0, ts_e.arena.flat.abs().max().item()), d   # (same last-bit freedom as the losses above)
     assert ts_g.t == ts_e.t
 
 
