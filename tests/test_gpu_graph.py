@@ -46,7 +46,7 @@ def test_graph_replay_matches_eager(dev):
     run = ts_g.capture(*batches[0])
     torch.cuda.synchronize()
     d0 = (ts_e.arena.flat - ts_g.arena.flat).abs().max().item()
-    assert d0 < 1e-6, d0
+    assert d0 < 1e-6 * max(1.0, ts_e.arena.flat.abs().max().item()), d0
     losses_e, losses_g = [], []
     for inp, lab in batches[1:]:
         losses_e.append(ts_e.step(inp, lab).item())
