@@ -205,6 +205,10 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the step as one hipGraph (single GPU, SGD, no dropout): the text-tower fork / join and the "
                     "tower-wide weight-gradient grid are captured too (LC2IS_GRAPH_OVERLAP=0: one captured stream)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI) | gloo (wiring tests on one GPU)")
+    ap.add_argument("--force-reducer", action="store_true",
+                    help="--gpus 1 only: run the DATA-PARALLEL configuration of the step on one GPU — a 1-rank process group on "
+                         "--backend, GradReducer attached (3-layer weight-gradient groups, bucketed all_reduce enqueues on RCCL's "
+                         "stream, event waits) — to price the DP path itself; the JSON line says config.dp_path_forced")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -222,7 +226,11 @@ def main():
     dev = torch.device("cuda", local_rank)
     reducer = None
     rccl_log = None
-    if world > 1:
+    forced_dp = args.force_reducer and world == 1
+    if forced_dp:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
+    if world > 1 or forced_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl" and "NCCL_DEBUG" not in os.environ:
             # record which algorithm / protocol RCCL picks over xGMI (ring vs tree / direct), per rank, into a file: the first
@@ -260,20 +268,20 @@ def main():
                     _cache["t"] = type(_te).forward(_te, input_ids, attention_mask).detach()
             return _cache["t"]
         _te.forward = _cached_text
-    if world > 1:
+    if world > 1 or forced_dp:
         reducer = GradReducer()
     ts = TrainStep(model, optimizer=args.optimizer, lr=1e-5, reducer=reducer)  # all_args.sh:15 LR
-    if world > 1:
+    if reducer is not None:
         reducer.broadcast_params(ts.arena.flat, src=0)
     inputs, labels = synth_batch(args.batch, in_size, out_size, args.text_len, 2 + rank, dev)
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if reducer is not None:
             dist.barrier()
             torch.cuda.synchronize()
 
-    use_graph = args.graph and world == 1 and args.optimizer == "sgd"
+    use_graph = args.graph and world == 1 and not forced_dp and args.optimizer == "sgd"
     for _ in range(args.warmup):
         loss = ts.step(inputs, labels)
     sync()
@@ -320,7 +328,9 @@ def main():
             "config": {"workload": f"BaseModelWithText {'ViT-B/16' if args.patch == 16 else 'ViT-L/14'} + CLIP-text + decoder + fused head/CE train step, "
                                    f"{in_size}x{in_size}, 151 classes, text len {args.text_len}, {args.optimizer}",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
-                       "parallelism": f"dp{world}", "params_M": round(ts.arena.numel / 1e6, 2)},
+                       "parallelism": f"dp{world}", "params_M": round(ts.arena.numel / 1e6, 2),
+                       **({"dp_path_forced": f"1-rank {args.backend} group: {getattr(reducer, 'collectives_last_step', None)} all_reduce "
+                                             "enqueues per step"} if forced_dp else {})},
             "final_loss": loss_val,
             **({"diagnostic": "LC2IS_BENCH_CACHED_TEXT: the text tower is skipped — NOT a benchmark result"} if diag_cached_text else {}),
             "roofline": {"bound": "mfma", "kernel": "large-tile LDS-DMA NT GEMM family: gemm_nt_pp_kernel<*> (persistent ping-pong 256x256), gemm_nt_w384_kernel (256x384, N = 768), gemm_nt_dma_kernel<256,256,2,4,*> (every launch of each 4th timed step)",
@@ -359,7 +369,7 @@ def main():
             except Exception as e:  # the baseline is a reported side number; never lose the GPU line over it
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or forced_dp:
         dist.barrier()
         dist.destroy_process_group()
 

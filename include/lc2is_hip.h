@@ -135,7 +135,7 @@ int lc2is_colsum_bf16(const void* dY, int ldy, float* db, int M, int N, int accu
  * (may be NULL in inference).  gamma/beta fp32, beta may be NULL (torch 2.10 bias=False drift).
  * replaces: nn.LayerNorm.forward at hf:CLIPEncoderLayer.forward:362-383, pre_layrnorm / final_layer_norm,
  *   norm1-3 of torch TransformerDecoderLayer (model/decoder.py:9). */
-int lc2is_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, void* y_bf16,
+int lc2is_layernorm_fwd(const void* x, int ldx, int x_is_bf16, const float* gamma, const float* beta, void* y_bf16,
                         int ldy, float* y_f32, int ldyf, float* mean, float* rstd, int M, int C, float eps,
                         lc2is_stream_t stream);
 
@@ -143,10 +143,10 @@ int lc2is_layernorm_fwd(const float* x, int ldx, const float* gamma, const float
  * `workspace` (>= lc2is_layernorm_bwd_workspace_bytes) and a second launch (deterministic).
  * dy is bf16 [M,C] (the dgrad GEMM's output) or, if dy_f32 != NULL, fp32. */
 size_t lc2is_layernorm_bwd_workspace_bytes(int M, int C);
-int lc2is_layernorm_bwd(const void* dy_bf16, int lddy, const float* dy_f32, int lddyf, const float* x,
-                        int ldx, const float* gamma, const float* mean, const float* rstd,
-                        const float* dres, int lddres, float* dx_f32, int lddx, void* dx_bf16, int lddxb,
-                        float* dgamma, float* dbeta, int accumulate, int M, int C, void* workspace,
+int lc2is_layernorm_bwd(const void* dy_bf16, int lddy, const float* dy_f32, int lddyf, const void* x,
+                        int ldx, int x_is_bf16, const float* gamma, const float* mean, const float* rstd,
+                        const void* dres, int lddres, int dres_is_bf16, float* dx_f32, int lddx, void* dx_bf16,
+                        int lddxb, float* dgamma, float* dbeta, int accumulate, int M, int C, void* workspace,
                         size_t workspace_bytes, lc2is_stream_t stream);
 
 /* Deferred parameter gradients: a lc2is_layernorm_bwd call with dgamma == dbeta == NULL leaves its per-block partial

@@ -37,55 +37,69 @@ def _dist():
     return None, 0, 1
 
 
-def save_checkpoint(model: nn.Module, out_dir: str | Path, train_step: int) -> Path:
+def _sidecar(f: Path, rank: int, world: int) -> Path:
+    """One dropout-stream sidecar PER RANK: ``step-N.rng.json`` in a single process, ``step-N.rng.rank<r>.json`` under
+    data parallelism (each rank writes and reads only its own: no collective anywhere in save or load)."""
+    return f.with_suffix(".rng.json") if world == 1 else f.with_name(f"{f.stem}.rng.rank{rank}.json")
+
+
+def save_checkpoint(model: nn.Module, out_dir: str | Path, train_step: int, write_model: bool | None = None) -> Path:
     """engine.py:186-190 — ``<out_dir>/checkpoints/step-<N>.pt`` holding ``model.state_dict()``.
 
-    Under data parallelism EVERY rank calls this (it contains a collective): the replicas hold the same parameters, so rank 0
-    alone writes the files; the dropout stream, however, differs per rank (``DropoutRng`` derives it from the torch seed AND
-    the rank), so the states of all ranks are gathered and the sidecar carries one entry per rank."""
-    dist, rank, world = _dist()
+    A plain write like the reference's ``Engine.save`` — **no collective, no barrier**: the usual ``if rank == 0:
+    save_checkpoint(...)`` of a data-parallel caller works, and so does calling it on every rank.  The replicas hold the same
+    parameters, so only rank 0 writes ``step-N.pt`` (``write_model`` overrides: True / False); the dropout stream, however,
+    differs per rank (``DropoutRng`` derives it from the torch seed AND the rank), so every rank THAT CALLS writes its own
+    small JSON sidecar.  A rank that did not call has no sidecar and resumes on the stream derived from its seed and rank."""
+    _, rank, world = _dist()
     d = Path(out_dir) / "checkpoints"
     f = d / f"step-{train_step}.pt"
-    # the dropout stream is not part of the reference's file (it would break the interchange): a JSON sidecar carries it, so a
-    # resumed run draws the masks the uninterrupted run would have drawn — on every rank
-    from .nn.base import DropoutRng
-    states = [DropoutRng.get_state()]
-    if dist is not None and world > 1:
-        states = [None] * world
-        dist.all_gather_object(states, DropoutRng.get_state())
-    if rank == 0:
-        d.mkdir(parents=True, exist_ok=True)
+    d.mkdir(parents=True, exist_ok=True)
+    if write_model if write_model is not None else rank == 0:
         torch.save({k: v.detach().cpu() for k, v in model.state_dict().items()}, f)
-        side = d / f"step-{train_step}.rng.json"
-        if any(st is not None for st in states):
-            side.write_text(json.dumps({"train_step": int(train_step), "world_size": world,
-                                        "dropout_rng_state": {str(r): st for r, st in enumerate(states)}}))
-        elif side.exists():
-            side.unlink()                      # never leave a stale stream beside a fresh step-N.pt
-    if dist is not None and world > 1:
-        dist.barrier()                         # the files exist when any rank returns
+    # the dropout stream is not part of the reference's file (it would break the interchange): a JSON sidecar carries it, so a
+    # resumed run draws the masks the uninterrupted run would have drawn — on every rank that saved
+    from .nn.base import DropoutRng
+    side, st = _sidecar(f, rank, world), DropoutRng.get_state()
+    if st is not None:
+        side.write_text(json.dumps({"train_step": int(train_step), "world_size": world, "rank": rank,
+                                    "dropout_rng_state": {str(rank): st}}))
+    elif side.exists():
+        side.unlink()                          # never leave a stale stream beside a fresh step-N.pt
     return f
 
 
+def _sidecar_state(side: Path, stem: str, rank: int, world: int):
+    """The dropout-stream state a sidecar holds for (this rank, this world size, this train step), or None.  Accepted forms:
+    the current one; round 4's single file with one entry per rank; and — in a single process only — the first format, a bare
+    ``{"dropout_rng_state": <int>}`` without step or world size.  Anything malformed or stale is ignored."""
+    try:
+        meta = json.loads(side.read_text())
+        st = meta["dropout_rng_state"]
+        if isinstance(st, int):                                    # first format: no step / world size recorded
+            return st if (world == 1 and "train_step" not in meta) else None
+        if stem != f"step-{int(meta['train_step'])}" or int(meta["world_size"]) != world:
+            return None
+        return int(st[str(rank)])
+    except (OSError, ValueError, KeyError, TypeError):
+        return None
+
+
 def load_checkpoint(model: nn.Module, path: str | Path, strict: bool = True):
-    """Load a reference ``step-N.pt`` (or one written by :func:`save_checkpoint`) into a drop-in model.  A dropout-stream
-    sidecar is adopted only when it names the same train step as the file and holds an entry for this rank at this world
-    size (a sidecar left behind by another run beside a reference ``step-N.pt`` is ignored: the stream then stays the one
-    derived from the torch seed and the rank)."""
+    """Load a reference ``step-N.pt`` (or one written by :func:`save_checkpoint`) into a drop-in model.  This rank's
+    dropout-stream sidecar is adopted only when it names the same train step as the file and this world size (a sidecar left
+    behind by another run beside a reference ``step-N.pt`` is ignored: the stream then stays the one derived from the torch
+    seed and the rank).  No collective: every rank reads only files."""
     path = Path(path)
     result = model.load_state_dict(_read_state(path), strict=strict)
-    side = path.with_suffix(".rng.json")
-    if side.is_file():
-        from .nn.base import DropoutRng
-        _, rank, world = _dist()
-        try:
-            meta = json.loads(side.read_text())
-            st = meta["dropout_rng_state"]
-            step_ok = path.stem == f"step-{meta['train_step']}"
-        except (ValueError, KeyError, TypeError):
-            st, step_ok = None, False
-        if isinstance(st, dict) and step_ok and int(meta.get("world_size", -1)) == world and str(rank) in st:
-            DropoutRng.set_state(st[str(rank)])
+    _, rank, world = _dist()
+    from .nn.base import DropoutRng
+    for side in (_sidecar(path, rank, world), path.with_suffix(".rng.json")):   # own file first, then round 4's combined file
+        if side.is_file():
+            st = _sidecar_state(side, path.stem, rank, world)
+            if st is not None:
+                DropoutRng.set_state(st)
+                break
     for m in model.modules():                      # bf16 weight shadows are rebuilt on the next forward
         if hasattr(m, "invalidate_shadows"):
             m.invalidate_shadows()

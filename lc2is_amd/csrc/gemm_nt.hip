@@ -937,7 +937,7 @@ __device__ __forceinline__ bf16x8_t lds_read_b128(unsigned addr) {   // by 32-bi
 }
 
 template <int ACT>
-__global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmNtArgs p, int ntiles) {
+__global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmNtArgs p, int ntiles, int stagger) {
   constexpr int BM = 256, BN = 256, WAVES_N = 4, BK = 64;
   constexpr int WM = 128, WN = 64, TM = 8, TN = 4;
   constexpr int STAGE = (BM + BN) * 128;
@@ -985,6 +985,20 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmNtArgs p, int ntile
   };
 
   int t = blockIdx.x;
+  if (stagger > 0 && gridDim.x == 256) {
+    // DE-SYNCHRONISED ROUNDS (round 5).  With every CU starting together, all 256 blocks reach their epilogues together: the
+    // matrix pipes idle while the chip's HBM write rate (not a CU's: 27 against 108 GB/s per CU, r03_store_overlap_probe) sets
+    // the epilogue's length, then HBM idles while everybody is in the K loop.  Block b starts `vb / 256 x stagger` late (vb:
+    // b with the 5 bits of its in-XCD index reversed — neighbours in launch order get far-apart delays, b % 8 = the XCD label
+    // xcd_remap relies on is kept) and walks tiles vb, vb + 256, ...: the blocks that take the extra tile of a ragged last round
+    // are the ones that started first.  Epilogues of some CUs then run under the K loops of the others.
+    const unsigned b = blockIdx.x;
+    const unsigned vb = ((__brev(b >> 3) >> 27) << 3) | (b & 7);
+    t = (int)vb;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+    const unsigned long long wait = (unsigned long long)vb * (unsigned)stagger / 256u;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+  }
   if (t >= ntiles) return;
   tile_offsets(t, lane0);
   if (wm == 1) issue_w(0);
@@ -1088,7 +1102,9 @@ int launch_pp_act(const GemmNtArgs& a, hipStream_t stream) {
   }
   const int ntiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
   const int grid = ntiles < lc2is_ncu() ? ntiles : lc2is_ncu();   // one block per CU of the budget (common.h)
-  hipLaunchKernelGGL(gemm_nt_pp_kernel<ACT>, dim3(grid), dim3(512), LDS, stream, a, ntiles);
+  const char* sg = getenv("LC2IS_GEMM_STAGGER_NS");   // (experiment: re-read per launch so that one process can A/B it)
+  const int stagger = sg ? atoi(sg) / 10 : 0;          // 100 MHz ticks
+  hipLaunchKernelGGL(gemm_nt_pp_kernel<ACT>, dim3(grid), dim3(512), LDS, stream, a, ntiles, stagger);
   return lc2is_check_launch();
 }
 

@@ -16,11 +16,17 @@ namespace {
 #endif
 constexpr int LN_MAXV = 8;  // float4 per lane -> C <= 2048 (kernels are instantiated for NV = 1,2,3,4,6,8)
 
+__device__ __forceinline__ float4 load_bf16x4(const bf16_t* p) {   // four consecutive bf16 (8-byte aligned) -> fp32
+  const uint2 pk = *reinterpret_cast<const uint2*>(p);
+  return make_float4(bf16_to_f32((bf16_t)(pk.x & 0xffff)), bf16_to_f32((bf16_t)(pk.x >> 16)),
+                     bf16_to_f32((bf16_t)(pk.y & 0xffff)), bf16_to_f32((bf16_t)(pk.y >> 16)));
+}
+
 // A wave walks rows blockIdx.x * 4 + wave, + 4 * gridDim.x, ... : gamma / beta are read once per wave instead of once per row and the
 // next row's x is requested before the current row's reductions (round 4; worth 0.2 % of the step: 1018 vs 1016 img/s against one
 // row per wave).  The arithmetic of a row is unchanged (bitwise the same outputs).
 template <int NV>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int ldx,
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const bf16_t* __restrict__ xb, int ldx,
                                                       const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, bf16_t* y, int ldy,
                                                       float* yf, int ldyf, float* mean_out, float* rstd_out,
@@ -38,6 +44,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   auto load_row = [&](int r, float4 (&dst)[NV]) __attribute__((always_inline)) {
+    if (xb) {   // bf16 residual stream (round 5): 8 bytes per lane and group, widened on the way in
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c4 = lane + 64 * i;
+        dst[i] = (c4 < C4) ? load_bf16x4(xb + (size_t)r * ldx + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      return;
+    }
     const float4* xr = reinterpret_cast<const float4*>(x + (size_t)r * ldx);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -97,9 +111,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 
 __device__ __forceinline__ float4 load_dy4(const bf16_t* dyb, const float* dyf, size_t off) {
   if (dyf) return *reinterpret_cast<const float4*>(dyf + off);
-  const uint2 pk = *reinterpret_cast<const uint2*>(dyb + off);
-  return make_float4(bf16_to_f32((bf16_t)(pk.x & 0xffff)), bf16_to_f32((bf16_t)(pk.x >> 16)),
-                     bf16_to_f32((bf16_t)(pk.y & 0xffff)), bf16_to_f32((bf16_t)(pk.y >> 16)));
+  return load_bf16x4(dyb + off);
 }
 
 // grid = nblk blocks of 4 waves; wave w of block b walks rows b*4+w, +4*nblk, ...
@@ -107,11 +119,11 @@ __device__ __forceinline__ float4 load_dy4(const bf16_t* dyb, const float* dyf, 
 template <int NV>
 __global__ __launch_bounds__(256, (NV <= 3 ? LN_BWD_OCC : NV == 4 ? 3 : NV <= 6 ? 2 : 1)) void ln_bwd_kernel(const bf16_t* __restrict__ dyb, int lddy,
                                                       const float* __restrict__ dyf, int lddyf,
-                                                      const float* __restrict__ x, int ldx,
+                                                      const float* __restrict__ x, const bf16_t* __restrict__ xb, int ldx,
                                                       const float* __restrict__ gamma,
                                                       const float* __restrict__ mean,
                                                       const float* __restrict__ rstd,
-                                                      const float* __restrict__ dres, int lddres,
+                                                      const float* __restrict__ dres, const bf16_t* __restrict__ dresb, int lddres,
                                                       float* dxf, int lddx, bf16_t* dxb, int lddxb,
                                                       float* ws, int M, int C) {
   __shared__ float red[4 * 2048];  // [wave][C <= 2048], reused for dgamma then dbeta
@@ -133,15 +145,21 @@ __global__ __launch_bounds__(256, (NV <= 3 ? LN_BWD_OCC : NV == 4 ? 3 : NV <= 6 
 #pragma unroll
     for (int i = 0; i < NV; ++i) {  // the residual-path gradient is fetched with the other operands, not after the reduction
       const int c4 = lane + 64 * i;
-      rv[i] = (dres && c4 < C4) ? *reinterpret_cast<const float4*>(dres + (size_t)row * lddres + 4 * c4)
-                                : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (dresb) rv[i] = (c4 < C4) ? load_bf16x4(dresb + (size_t)row * lddres + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      else rv[i] = (dres && c4 < C4) ? *reinterpret_cast<const float4*>(dres + (size_t)row * lddres + 4 * c4)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c4 = lane + 64 * i;
       if (c4 < C4) {
-        const f32x4_t xv_ = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(x + (size_t)row * ldx + 4 * c4));
-        const float4 xv = make_float4(xv_[0], xv_[1], xv_[2], xv_[3]);
+        float4 xv;
+        if (xb) {
+          xv = load_bf16x4(xb + (size_t)row * ldx + 4 * c4);
+        } else {
+          const f32x4_t xv_ = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(x + (size_t)row * ldx + 4 * c4));
+          xv = make_float4(xv_[0], xv_[1], xv_[2], xv_[3]);
+        }
         dy[i] = load_dy4(dyb, dyf, (size_t)row * ldy_ + 4 * c4);
         xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
         const float a = dy[i].x * gm[i].x, b = dy[i].y * gm[i].y, c = dy[i].z * gm[i].z, d = dy[i].w * gm[i].w;
@@ -221,16 +239,18 @@ static int ln_fwd_blocks(int M) {
   return need < cap ? need : (cap > 0 ? cap : need);
 }
 
-extern "C" int lc2is_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta,
+extern "C" int lc2is_layernorm_fwd(const void* x, int ldx, int x_is_bf16, const float* gamma, const float* beta,
                                    void* y_bf16, int ldy, float* y_f32, int ldyf, float* mean, float* rstd,
                                    int M, int C, float eps, lc2is_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!x || !gamma || (!y_bf16 && !y_f32)) return LC2IS_ERR_NULL;
+  const float* xf = x_is_bf16 ? nullptr : (const float*)x;
+  const bf16_t* xb = x_is_bf16 ? (const bf16_t*)x : nullptr;
   if (M <= 0 || C <= 0 || C % 4 || C > LN_MAXV * 256) return LC2IS_ERR_SHAPE;
   if (ldx < C || ldx % 4 || (y_bf16 && (ldy < C || ldy % 4)) || (y_f32 && (ldyf < C || ldyf % 4)))
     return LC2IS_ERR_SHAPE;
 #define LN_FWD(NV_)                                                                                  \
-  hipLaunchKernelGGL(ln_fwd_kernel<NV_>, dim3(ln_fwd_blocks(M)), dim3(256), 0, stream, x, ldx, gamma, beta, \
+  hipLaunchKernelGGL(ln_fwd_kernel<NV_>, dim3(ln_fwd_blocks(M)), dim3(256), 0, stream, xf, xb, ldx, gamma, beta, \
                      (bf16_t*)y_bf16, ldy, y_f32, ldyf, mean, rstd, M, C, eps)
   const int nv = (C / 4 + 63) / 64;
   if (nv <= 1) LN_FWD(1); else if (nv == 2) LN_FWD(2); else if (nv == 3) LN_FWD(3);
@@ -245,12 +265,16 @@ extern "C" size_t lc2is_layernorm_bwd_workspace_bytes(int M, int C) {
 }
 
 extern "C" int lc2is_layernorm_bwd(const void* dy_bf16, int lddy, const float* dy_f32, int lddyf,
-                                   const float* x, int ldx, const float* gamma, const float* mean,
-                                   const float* rstd, const float* dres, int lddres, float* dx_f32, int lddx,
-                                   void* dx_bf16, int lddxb, float* dgamma, float* dbeta, int accumulate,
+                                   const void* x, int ldx, int x_is_bf16, const float* gamma, const float* mean,
+                                   const float* rstd, const void* dres, int lddres, int dres_is_bf16, float* dx_f32,
+                                   int lddx, void* dx_bf16, int lddxb, float* dgamma, float* dbeta, int accumulate,
                                    int M, int C, void* workspace, size_t workspace_bytes,
                                    lc2is_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  const float* xf = x_is_bf16 ? nullptr : (const float*)x;
+  const bf16_t* xb = x_is_bf16 ? (const bf16_t*)x : nullptr;
+  const float* dresf = dres_is_bf16 ? nullptr : (const float*)dres;
+  const bf16_t* dresb = dres_is_bf16 ? (const bf16_t*)dres : nullptr;
   if ((!dy_bf16 && !dy_f32) || !x || !gamma || !mean || !rstd || (!dx_f32 && !dx_bf16)) return LC2IS_ERR_NULL;
   if (M <= 0 || C <= 0 || C % 4 || C > LN_MAXV * 256) return LC2IS_ERR_SHAPE;
   if (ldx < C || ldx % 4) return LC2IS_ERR_SHAPE;
@@ -262,7 +286,7 @@ extern "C" int lc2is_layernorm_bwd(const void* dy_bf16, int lddy, const float* d
   const int nblk = ln_bwd_blocks(M, C);
 #define LN_BWD(NV_)                                                                                   \
   hipLaunchKernelGGL(ln_bwd_kernel<NV_>, dim3(nblk), dim3(256), 0, stream, (const bf16_t*)dy_bf16, lddy, \
-                     dy_f32, lddyf, x, ldx, gamma, mean, rstd, dres, lddres, dx_f32, lddx,              \
+                     dy_f32, lddyf, xf, xb, ldx, gamma, mean, rstd, dresf, dresb, lddres, dx_f32, lddx,  \
                      (bf16_t*)dx_bf16, lddxb, (float*)workspace, M, C)
   const int nv = (C / 4 + 63) / 64;
   if (nv <= 1) LN_BWD(1); else if (nv == 2) LN_BWD(2); else if (nv == 3) LN_BWD(3);

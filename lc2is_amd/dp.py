@@ -41,6 +41,7 @@ class GradReducer:
         import os
         self.cu_reserve = max(0, min(128, int(os.environ.get("LC2IS_DP_CU_RESERVE", "0"))))
         self._budget_on = False
+        self.collectives_last_step = 0       # all_reduce calls issued by the most recent finished step
 
     # -- wiring ------------------------------------------------------------------------------------------------
     def attach(self, model, arena) -> None:
@@ -151,10 +152,13 @@ class GradReducer:
                 self._flush_bucket(key)
                 self._done.add(key)
                 self.reduce_ranges(self._flat, self._subtract(ranges, self._early.get(key, [])))
-        for w in self._pending:
-            w.wait()
-        self._pending.clear()
-        self._set_budget(False)
+        try:
+            for w in self._pending:
+                w.wait()
+        finally:                             # (an exception must not leave the planners on a reduced CU budget)
+            self.collectives_last_step = len(self._pending)
+            self._pending.clear()
+            self._set_budget(False)
 
     def broadcast_params(self, flat_params: torch.Tensor, src: int = 0) -> None:
         dist.broadcast(flat_params, src=src, group=self.group)

@@ -180,9 +180,19 @@ def _stack_fwd(x, stack: _Stack, sh, a: ClipArch, B: int, S: int, kbias, causal:
     return x, saved
 
 
-def _stack_bwd(g32, g16, stack: _Stack, sh, saved, a: ClipArch, B: int, S: int, kbias, causal: bool, on_layer_done=None):
-    """Backward of _stack_fwd.  g32/g16: gradient wrt the stack output (fp32 + bf16 twin).
-    Returns the gradient wrt the stack input as (fp32, bf16)."""
+# The gradient stream of the towers — the backward's counterpart of the residual stream — travels in bf16 (round 5): every
+# consumer but the next LayerNorm backward is an MFMA operand anyway, and a LayerNorm backward that reads and writes ONE bf16
+# stream moves 10 bytes per element instead of 16 (it is HBM-bound: 82 -> ~55 us per launch at M = 32 800, 25 launches per step).
+# The stream is re-rounded at each of the 2 x layers residual joins (relative 2^-9 each, unbiased): ~0.5 % after 24 joins, below
+# the 1-2 % the bf16 operands already cost the gradients (tests/test_gpu_parity2.py).  LC2IS_GRAD_STREAM=f32 keeps the fp32 chain.
+_GRAD_STREAM_BF16 = __import__('os').environ.get("LC2IS_GRAD_STREAM", "bf16") != "f32"
+
+
+def _stack_bwd(g32, g16, stack: _Stack, sh, saved, a: ClipArch, B: int, S: int, kbias, causal: bool, on_layer_done=None,
+               final_f32: bool = True):
+    """Backward of _stack_fwd.  g32/g16: gradient wrt the stack output (fp32 + bf16 twin; with the bf16 gradient stream only
+    g16 is read).  Returns the gradient wrt the stack input as (fp32, bf16); the fp32 form is None when the stream is bf16 and
+    `final_f32` is False."""
     C, H = a.hidden, a.heads
     D = C // H
     scale = D ** -0.5
@@ -199,6 +209,10 @@ def _stack_bwd(g32, g16, stack: _Stack, sh, saved, a: ClipArch, B: int, S: int, 
     pair = int(__import__('os').environ.get('LC2IS_WGRAD_PAIR', str(default_pair)))
     batch, waiting = WgradBatch(), []
     batch.__enter__()
+    lean = _GRAD_STREAM_BF16
+    if lean:
+        g32 = None
+    first = stack.layers[0]
     try:
         for layer, s, sv in zip(reversed(stack.layers), reversed(sh), reversed(saved)):
             x, m1, r1, h, qkv, o, lse, x_mid, m2, r2, h2, z, act = sv
@@ -210,8 +224,9 @@ def _stack_bwd(g32, g16, stack: _Stack, sh, saved, a: ClipArch, B: int, S: int, 
             dh2, _, _ = ops.gemm_nt(dz, s["w1T"], None)
             dg, accg = vec_grad(layer.layer_norm2.weight)
             db, _ = vec_grad(layer.layer_norm2.bias)
-            gm32, gm16, _, _ = ops.layernorm_bwd(dh2, x_mid, layer.layer_norm2.weight, m2, r2, dres=g32, dgamma=dg,
-                                                 dbeta=db, accumulate=accg, need_param_grads=dg is not None)
+            gm32, gm16, _, _ = ops.layernorm_bwd(dh2, x_mid, layer.layer_norm2.weight, m2, r2, dres=g16 if lean else g32,
+                                                 dgamma=dg, dbeta=db, accumulate=accg, want_f32=not lean,
+                                                 need_param_grads=dg is not None)
             # x_mid = x + out_proj(attn(qkv(LN1(x))))
             linear_bwd_params(gm16, o, at.out_proj.weight, at.out_proj.bias)
             do, _, _ = ops.gemm_nt(gm16, s["woT"], None)
@@ -223,8 +238,10 @@ def _stack_bwd(g32, g16, stack: _Stack, sh, saved, a: ClipArch, B: int, S: int, 
             dh, _, _ = ops.gemm_nt(dqkv, s["wqkvT"], None)
             dg, accg = vec_grad(layer.layer_norm1.weight)
             db, _ = vec_grad(layer.layer_norm1.bias)
-            g32, g16, _, _ = ops.layernorm_bwd(dh, x, layer.layer_norm1.weight, m1, r1, dres=gm32, dgamma=dg, dbeta=db,
-                                               accumulate=accg, need_param_grads=dg is not None)
+            g32, g16, _, _ = ops.layernorm_bwd(dh, x, layer.layer_norm1.weight, m1, r1, dres=gm16 if lean else gm32,
+                                               dgamma=dg, dbeta=db, accumulate=accg,
+                                               want_f32=(not lean) or (final_f32 and layer is first),
+                                               need_param_grads=dg is not None)
             waiting.append(layer)
             if len(waiting) >= pair:
                 batch.flush()
@@ -364,15 +381,21 @@ class ImageEncoderCLIP(HipModule):
         C = a.hidden
         if keep_cls:
             g32 = gout.reshape(B * (P + 1), C).float()
+            g16 = ops.cast_bf16(g32)
+        elif _GRAD_STREAM_BF16:   # the patch rows go straight into the bf16 stream (CLS rows: zero gradient)
+            g32 = None
+            g16 = torch.zeros(B * (P + 1), C, dtype=torch.bfloat16, device=gout.device)
+            ops.rows_copy(gout.reshape(B * P, C).float().contiguous(), P, 0, P + 1, 1, B, P, dst_bf16=g16)
         else:
             g32 = torch.zeros(B * (P + 1), C, dtype=torch.float32, device=gout.device)
             ops.rows_copy(gout.reshape(B * P, C).float().contiguous(), P, 0, P + 1, 1, B, P, dst_f32=g32)
-        g16 = ops.cast_bf16(g32)
-        g32, _ = _stack_bwd(g32, g16, self.enc.encoder, sh["layers"], saved["layers"], a, B, P + 1, None, False,
-                            on_layer_done=self._part_grads_ready if self._part_ready_cb is not None else None)
+            g16 = ops.cast_bf16(g32)
+        g32, g16 = _stack_bwd(g32, g16, self.enc.encoder, sh["layers"], saved["layers"], a, B, P + 1, None, False,
+                              on_layer_done=self._part_grads_ready if self._part_ready_cb is not None else None,
+                              final_f32=False)
         dg, accg = vec_grad(self.enc.pre_layrnorm.weight)
         db, _ = vec_grad(self.enc.pre_layrnorm.bias)
-        dx0, _, _, _ = ops.layernorm_bwd(g32, saved["x0"], self.enc.pre_layrnorm.weight, saved["m0"], saved["r0"],
+        dx0, _, _, _ = ops.layernorm_bwd(g32 if g32 is not None else g16, saved["x0"], self.enc.pre_layrnorm.weight, saved["m0"], saved["r0"],
                                          dgamma=dg, dbeta=db, accumulate=accg, want_bf16=False,
                                          need_param_grads=dg is not None)
         emb = self.enc.embeddings

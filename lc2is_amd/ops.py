@@ -26,11 +26,11 @@ _ARGTYPES = {
     "lc2is_gemm_tn_bf16": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _Z, _P],
     "lc2is_colsum_workspace_bytes": [_I, _I],
     "lc2is_colsum_bf16": [_P, _I, _P, _I, _I, _I, _P, _Z, _P],
-    "lc2is_layernorm_fwd": [_P, _I, _P, _P, _P, _I, _P, _I, _P, _P, _I, _I, _F, _P],
+    "lc2is_layernorm_fwd": [_P, _I, _I, _P, _P, _P, _I, _P, _I, _P, _P, _I, _I, _F, _P],
     "lc2is_layernorm_bwd_partials": [_I, _I],
     "lc2is_ln_partials_reduce": [_P, _I, _P],
     "lc2is_layernorm_bwd_workspace_bytes": [_I, _I],
-    "lc2is_layernorm_bwd": [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I,
+    "lc2is_layernorm_bwd": [_P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _P, _I, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I,
                             _P, _Z, _P],
     "lc2is_attention_fwd": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "lc2is_attention_bwd": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P,
@@ -303,15 +303,16 @@ def colsum(dy: torch.Tensor, db: torch.Tensor | None = None, accumulate: bool = 
 def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor | None, eps: float = 1e-5, *,
                   save_stats: bool = True, out_bf16: torch.Tensor | bool | None = True,
                   out_f32: torch.Tensor | bool | None = None):
-    """x fp32 [M,C] -> (y_bf16, y_f32, mean, rstd)."""
-    _chk(x, torch.float32, "x"); _chk(gamma, torch.float32, "gamma", 1); _chk(beta, torch.float32, "beta", 1)
+    """x fp32 or bf16 [M,C] (the residual stream) -> (y_bf16, y_f32, mean, rstd)."""
+    xb = x.dtype == torch.bfloat16
+    _chk(x, torch.bfloat16 if xb else torch.float32, "x"); _chk(gamma, torch.float32, "gamma", 1); _chk(beta, torch.float32, "beta", 1)
     M, Cc = x.shape
     dev = x.device
     yb = _out(out_bf16, (M, Cc), torch.bfloat16, dev)
     yf = _out(out_f32, (M, Cc), torch.float32, dev)
     mean = torch.empty((M,), dtype=torch.float32, device=dev) if save_stats else None
     rstd = torch.empty((M,), dtype=torch.float32, device=dev) if save_stats else None
-    rc = _fn("lc2is_layernorm_fwd")(_ptr(x), _ld(x), _ptr(gamma), _ptr(beta), _ptr(yb), _ld(yb), _ptr(yf),
+    rc = _fn("lc2is_layernorm_fwd")(_ptr(x), _ld(x), int(xb), _ptr(gamma), _ptr(beta), _ptr(yb), _ld(yb), _ptr(yf),
                                     _ld(yf), _ptr(mean), _ptr(rstd), M, Cc, float(eps), _stream())
     _lib.check(rc, f"layernorm_fwd M={M} C={Cc}")
     return yb, yf, mean, rstd
@@ -321,15 +322,18 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: 
                   rstd: torch.Tensor, *, dres: torch.Tensor | None = None, dgamma: torch.Tensor | None = None,
                   dbeta: torch.Tensor | None = None, accumulate: bool = False, want_f32: bool = True,
                   want_bf16: bool = True, need_param_grads: bool = True):
-    """Returns (dx_f32, dx_bf16, dgamma, dbeta).  dy is bf16 or fp32 [M,C]."""
+    """Returns (dx_f32, dx_bf16, dgamma, dbeta).  dy, x (the residual stream the forward normalised) and dres (the gradient
+    arriving over the residual path) are each bf16 or fp32 [M,C]."""
     M, Cc = x.shape
     dev = x.device
     dyb = dy if dy.dtype == torch.bfloat16 else None
     dyf = dy if dy.dtype == torch.float32 else None
     if dyb is None and dyf is None:
         raise RuntimeError("lc2is_amd.layernorm_bwd: dy must be bf16 or fp32")
-    _chk(dyb, torch.bfloat16, "dy"); _chk(dyf, torch.float32, "dy"); _chk(x, torch.float32, "x")
-    _chk(dres, torch.float32, "dres")
+    xb = x.dtype == torch.bfloat16
+    rb = dres is not None and dres.dtype == torch.bfloat16
+    _chk(dyb, torch.bfloat16, "dy"); _chk(dyf, torch.float32, "dy"); _chk(x, torch.bfloat16 if xb else torch.float32, "x")
+    _chk(dres, torch.bfloat16 if rb else torch.float32, "dres")
     dxf = torch.empty((M, Cc), dtype=torch.float32, device=dev) if want_f32 else None
     dxb = torch.empty((M, Cc), dtype=torch.bfloat16, device=dev) if want_bf16 else None
     if need_param_grads:
@@ -349,8 +353,8 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: 
     else:
         ws = workspace(nbytes, dev, "ln_bwd")
         pg, pb = dgamma, dbeta
-    rc = _fn("lc2is_layernorm_bwd")(_ptr(dyb), _ld(dyb), _ptr(dyf), _ld(dyf), _ptr(x), _ld(x), _ptr(gamma),
-                                    _ptr(mean), _ptr(rstd), _ptr(dres), _ld(dres), _ptr(dxf), _ld(dxf),
+    rc = _fn("lc2is_layernorm_bwd")(_ptr(dyb), _ld(dyb), _ptr(dyf), _ld(dyf), _ptr(x), _ld(x), int(xb), _ptr(gamma),
+                                    _ptr(mean), _ptr(rstd), _ptr(dres), _ld(dres), int(rb), _ptr(dxf), _ld(dxf),
                                     _ptr(dxb), _ld(dxb), _ptr(pg), _ptr(pb), int(accumulate), M, Cc,
                                     _ptr(ws), ws.numel(), _stream())
     _lib.check(rc, f"layernorm_bwd M={M} C={Cc}")

@@ -115,7 +115,10 @@ def _rng_worker(rank, world, port, tmp, q):
     torch.manual_seed(11)                                   # the same torch seed everywhere: the rank makes the streams differ
     first = [DropoutRng.next_seed() for _ in range(2)]
     m = torch.nn.Linear(4, 4)
-    f = Cc.save_checkpoint(m, tmp, 7)                       # every rank calls (collective); rank 0 writes
+    f = Cc.save_checkpoint(m, tmp, 7)                       # every rank calls; rank 0 writes step-7.pt, each rank its own sidecar
+    if rank == 0:                                           # the usual DP pattern must not hang: a plain write, no collective
+        Cc.save_checkpoint(m, tmp + "/rank0_only", 8)
+    dist.barrier()                                          # (test-side: rank 1 loads what rank 0 wrote)
     nxt = [DropoutRng.next_seed() for _ in range(3)]       # what the uninterrupted run draws next on THIS rank
     DropoutRng.manual_seed(12345)                           # a resumed process starts somewhere else
     Cc.load_checkpoint(m, f)
@@ -125,8 +128,9 @@ def _rng_worker(rank, world, port, tmp, q):
 
 
 def test_dropout_rng_sidecar_is_per_rank_under_data_parallelism(tmp_path):
-    """under DP each rank's dropout stream is derived from seed + rank; the sidecar must carry every
-    rank's state (rank 0 writes, after an all_gather_object) so that after a resume rank r continues ITS stream — not rank 0's."""
+    """under DP each rank's dropout stream is derived from seed + rank, so after a resume rank r must
+    continue ITS stream — not rank 0's.  ADVICE round 4 (medium): save_checkpoint is a plain write like Engine.save (no
+    collective): every rank writes its own sidecar, and `if rank == 0: save_checkpoint(...)` returns."""
     import os
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -143,8 +147,36 @@ def test_dropout_rng_sidecar_is_per_rank_under_data_parallelism(tmp_path):
     assert first0 != first1 and nxt0 != nxt1                # the ranks draw different masks
     assert res0 == nxt0 and res1 == nxt1                    # and each resumes its own stream
     import json
-    meta = json.loads((tmp_path / "checkpoints" / "step-7.rng.json").read_text())
-    assert meta["train_step"] == 7 and meta["world_size"] == 2 and set(meta["dropout_rng_state"]) == {"0", "1"}
+    for r in range(2):
+        meta = json.loads((tmp_path / "checkpoints" / f"step-7.rng.rank{r}.json").read_text())
+        assert meta["train_step"] == 7 and meta["world_size"] == 2 and set(meta["dropout_rng_state"]) == {str(r)}
+    only = tmp_path / "rank0_only" / "checkpoints"
+    assert (only / "step-8.pt").is_file() and (only / "step-8.rng.rank0.json").is_file()
+    assert not (only / "step-8.rng.rank1.json").exists()
+
+
+def test_older_sidecar_formats(tmp_path):
+    """Round 4's combined file (one entry per rank) and the first format (a bare state, single process only) are still read;
+    malformed files are ignored instead of raising."""
+    import json
+    from lc2is_amd.nn.base import DropoutRng
+    m = torch.nn.Linear(3, 3)
+    torch.manual_seed(3)
+    DropoutRng.next_seed()
+    f = C.save_checkpoint(m, tmp_path, 5)
+    side = f.with_suffix(".rng.json")
+    side.write_text(json.dumps({"train_step": 5, "world_size": 1, "dropout_rng_state": {"0": 1234}}))   # round 4
+    C.load_checkpoint(m, f)
+    assert DropoutRng.get_state() == 1234
+    side.write_text(json.dumps({"dropout_rng_state": 777}))                                              # first format
+    C.load_checkpoint(m, f)
+    assert DropoutRng.get_state() == 777
+    for bad in ('{"train_step": 5, "world_size": "x", "dropout_rng_state": {"0": 1}}', '{"dropout_rng_state": {"0": 1}}',
+                'not json', '{"train_step": 5, "world_size": 1, "dropout_rng_state": {"0": "y"}}'):
+        side.write_text(bad)
+        DropoutRng.manual_seed(42)
+        C.load_checkpoint(m, f)
+        assert DropoutRng.get_state() == 42
 
 
 def test_stale_dropout_sidecar_is_ignored(tmp_path):

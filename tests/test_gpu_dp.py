@@ -143,3 +143,86 @@ def test_bench_two_ranks_gloo_end_to_end(dev, tmp_path):
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 4 and rec["config"]["parallelism"] == "dp2"
     assert rec["scaling"] == "weak" and rec["value"] > 0 and rec["final_loss"] == rec["final_loss"]
     assert "cpu_baseline" not in rec                     # the CPU baseline belongs to the N = 1 line only
+
+
+def _rccl_one_rank_worker(port, out_path):
+    """Fresh process: the 1-rank RCCL group is created BEFORE any other GPU call, then one DP step (GradReducer attached: layer
+    groups, bucketed all_reduce on RCCL's stream, event waits, 1/world folded into SGD) and one plain step on the same batch."""
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    torch.cuda.set_device(dev)
+    from lc2is_amd.dp import GradReducer
+    from lc2is_amd.step import TrainStep
+    m_dp, fx = _build(dev)
+    m_1, _ = _build(dev)
+    red = GradReducer(bucket_elems=100_000)
+    calls = []
+    orig_all_reduce = dist.all_reduce
+
+    def recording_all_reduce(t, *a, **kw):
+        calls.append(int(t.numel()))
+        return orig_all_reduce(t, *a, **kw)
+
+    dist.all_reduce = recording_all_reduce
+    ts_dp = TrainStep(m_dp, optimizer="sgd", lr=0.05, reducer=red)
+    red.broadcast_params(ts_dp.arena.flat, src=0)
+    ts_1 = TrainStep(m_1, optimizer="sgd", lr=0.05)
+    inputs = {k: fx[k].to(dev) for k in ("pixel_values", "input_ids", "attention_mask")}
+    labels = fx["labels"].to(dev)
+    out = {"losses_dp": [], "losses_1": []}
+    for _ in range(3):                       # several steps: the collectives of step k+1 are enqueued behind the waits of step k
+        out["losses_dp"].append(float(ts_dp.step(inputs, labels).item()))
+        out["losses_1"].append(float(ts_1.step(inputs, labels).item()))
+    torch.cuda.synchronize()
+    out.update(flat_dp=ts_dp.arena.flat.cpu(), flat_1=ts_1.arena.flat.cpu(), grad_dp=ts_dp.arena.grad.cpu(),
+               grad_1=ts_1.arena.grad.cpu(), ncalls=len(calls), nelem=sum(calls), arena=ts_dp.arena.numel,
+               pelems=sum(q.numel() for q in m_dp.parameters()), last=red.collectives_last_step)
+    torch.save(out, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_rank_rccl_step_matches_plain_step(dev, tmp_path):
+    """the `nccl` (= RCCL) branch of the reducer on the ONE GPU of the test box.  World size 1 moves no bytes
+    between devices, but everything else is real: RCCL's communicator and stream, async work handles, the compute stream's
+    waits on them.  A sum over one rank is the identity, so the DP step must leave exactly the plain step's gradients except
+    where the DP plan differs (weight gradients in 3-layer groups: another split-K count, same math) — compared to 1e-5 of the
+    gradient norm — and every arena element must have been reduced exactly once."""
+    ctx = mp.get_context("spawn")
+    port = 29600 + os.getpid() % 300
+    outp = tmp_path / "rccl1.pt"
+    p = ctx.Process(target=_rccl_one_rank_worker, args=(port, str(outp)))
+    p.start()
+    p.join(timeout=300)
+    if p.is_alive():
+        p.terminate(); p.join(30)
+        if p.is_alive():
+            p.kill(); p.join()
+        pytest.fail("the 1-rank RCCL worker did not finish within 300 s")
+    assert p.exitcode == 0, p.exitcode
+    r = torch.load(outp, weights_only=True)
+    assert r["ncalls"] >= 3 * 4 and r["last"] * 3 == r["ncalls"]
+    # every gradient element is all-reduced exactly once per step (alignment padding between parameters may or may not ride along)
+    assert 3 * r["pelems"] <= r["nelem"] <= 3 * r["arena"], (r["nelem"], r["pelems"], r["arena"])
+    assert r["losses_dp"] == pytest.approx(r["losses_1"], abs=1e-5)
+    gn = r["grad_1"].norm().item()
+    assert ((r["grad_dp"] - r["grad_1"]).norm().item()) < 1e-5 * gn
+    assert (r["flat_dp"] - r["flat_1"]).abs().max().item() < 1e-6
+
+
+def test_bench_force_reducer_one_gpu_rccl(dev):
+    """`bench.py --gpus 1 --force-reducer`: the DP configuration of the step priced on one GPU over a 1-rank RCCL group."""
+    import json
+    import subprocess
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "2", "--in-size", "128",
+           "--force-reducer", "--no-cpu-baseline"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT=str(29350 + os.getpid() % 50))
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and "dp_path_forced" in out["config"] and out["value"] > 0

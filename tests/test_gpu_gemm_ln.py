@@ -390,6 +390,40 @@ def test_layernorm_fwd_bwd(dev, M, C):
     assert _rel(dxf2, xd.grad) < 1e-5
 
 
+@pytest.mark.parametrize("M,C", [(300, 768), (77, 1024), (1025, 64)])
+def test_layernorm_bf16_streams(dev, M, C):
+    """Round 5: the residual stream (x) and the gradient stream (dres) may arrive in bf16.  The kernels widen them on the way
+    in and otherwise run the fp32 arithmetic, so against fp64 of the SAME bf16-valued inputs the fp32 outputs are exact to
+    fp32 rounding, and feeding the widened tensors through the fp32 entry gives bitwise the same result."""
+    from lc2is_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(C * 3 + M)
+    xb = _bf((torch.randn(M, C, generator=g) * 2 + 0.5).to(dev))
+    gamma = (1 + 0.1 * torch.randn(C, generator=g)).to(dev)
+    beta = (0.1 * torch.randn(C, generator=g)).to(dev)
+    yb, yf, mean, rstd = ops.layernorm_fwd(xb, gamma, beta, 1e-5, out_bf16=True, out_f32=True)
+    yb2, yf2, mean2, rstd2 = ops.layernorm_fwd(xb.float(), gamma, beta, 1e-5, out_bf16=True, out_f32=True)
+    assert torch.equal(yf, yf2) and torch.equal(yb, yb2) and torch.equal(mean, mean2) and torch.equal(rstd, rstd2)
+    xd = xb.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xd, (C,), gd, bd, 1e-5)
+    assert (yf.double() - ref).abs().max().item() < 2e-5
+    dyb = _bf(torch.randn(M, C, generator=g).to(dev))
+    dresb = _bf(torch.randn(M, C, generator=g).to(dev))
+    ref.backward(dyb.double())
+    want = xd.grad + dresb.double()
+    for x_in, r_in in ((xb, dresb), (xb.float(), dresb), (xb, dresb.float())):
+        dxf, dxb, dg, db = ops.layernorm_bwd(dyb, x_in, gamma, mean, rstd, dres=r_in)
+        assert _rel(dxf, want) < 1e-5
+        assert _rel(dxb.float(), want) < 4e-3
+        assert _rel(dg, gd.grad) < 1e-5 and _rel(db, bd.grad) < 1e-5
+    a = ops.layernorm_bwd(dyb, xb, gamma, mean, rstd, dres=dresb)
+    b = ops.layernorm_bwd(dyb, xb.float(), gamma, mean, rstd, dres=dresb.float())
+    assert all(torch.equal(u, v) for u, v in zip(a, b))
+    # bf16-only output (what the towers' backward uses): no fp32 tensor is written
+    dxf3, dxb3, _, _ = ops.layernorm_bwd(dyb, xb, gamma, mean, rstd, dres=dresb, want_f32=False)
+    assert dxf3 is None and torch.equal(dxb3, a[1])
+
+
 def test_layernorm_bwd_deferred_param_grads_are_bitwise_equal(dev):
     """The dgamma / dbeta reductions of several LayerNorm backward calls in one grouped launch (ops.ln_defer_begin/flush,
     opened by nn.base.WgradBatch): same fixed-order sums as the per-call second launch, incl. accumulate and a vector that

@@ -35,26 +35,37 @@ def _batch(dev, seed):
 
 
 def test_graph_replay_matches_eager(dev):
+    """Eager and replayed steps from the same parameters on the same batches.  The two are the same arithmetic except for the
+    weight-gradient plan (whole tower in one grid eagerly, per-layer groups under capture: another split-K count, fp32 sums in
+    another order), so losses agree to fp32 rounding of an O(10) loss and the parameter UPDATES to 1e-4 of their size.
+    The learning rate keeps the random-init model in the regime training runs in (round 4 trained it at lr = 0.05 into a loss
+    of 2e4 — a diverged trajectory amplifies last-bit differences and says nothing about the capture)."""
     from lc2is_amd.step import TrainStep
     batches = [_batch(dev, s) for s in range(4)]
     m_e, m_g = _model(dev), _model(dev)
     m_g.load_state_dict(m_e.state_dict())
-    ts_e, ts_g = TrainStep(m_e, optimizer="sgd", lr=0.05), TrainStep(m_g, optimizer="sgd", lr=0.05)
+    lr = 1e-3
+    ts_e, ts_g = TrainStep(m_e, optimizer="sgd", lr=lr), TrainStep(m_g, optimizer="sgd", lr=lr)
+    start = ts_e.arena.flat.clone()
     # capture() runs 2 real warm-up steps on the first batch, then records (does not run) the captured one
     for _ in range(2):
         ts_e.step(*batches[0])
     run = ts_g.capture(*batches[0])
     torch.cuda.synchronize()
     d0 = (ts_e.arena.flat - ts_g.arena.flat).abs().max().item()
-    assert d0 < 1e-6 * max(1.0, ts_e.arena.flat.abs().max().item()), d0
+    assert d0 < 1e-6, d0
     losses_e, losses_g = [], []
     for inp, lab in batches[1:]:
         losses_e.append(ts_e.step(inp, lab).item())
         losses_g.append(run(inp, lab).item())
     torch.cuda.synchronize()
-    assert losses_e == pytest.approx(losses_g, rel=2e-6, abs=1e-5), (losses_e, losses_g)   # (the head scatters with fp32 atomics: the last bit of a loss of 2e4 is 2e-3)
+    assert max(losses_e) < 20.0, losses_e                       # still a sane cross-entropy over 151 classes
+    assert losses_e == pytest.approx(losses_g, abs=1e-5), (losses_e, losses_g)
     d = (ts_e.arena.flat - ts_g.arena.flat).abs().max().item()
-    assert d < 1e-6 * max(1.0, ts_e.arena.flat.abs().max().item()), d   # (same last-bit freedom as the losses above)
+    assert d < 1e-6, d
+    upd_e, upd_g = ts_e.arena.flat - start, ts_g.arena.flat - start
+    assert upd_e.norm().item() > 0
+    assert ((upd_e - upd_g).norm() / upd_e.norm()).item() < 1e-4
     assert ts_g.t == ts_e.t
 
 
