@@ -189,27 +189,6 @@ int lc2is_attention_bwd(const void* Q, int ldq, const void* K, int ldk, const vo
                         int lddk, void* dV, int lddv, const float* lse2, float* delta, const float* kbias,
                         int B, int H, int Sq, int Sk, int D, float scale, int causal, lc2is_stream_t stream);
 
-/* Fused form of lc2is_attention_bwd: a streaming prologue (lc2is_attention_delta: delta = rowsum(dO*O)) and ONE main
- * kernel that executes the algorithm's five matrix products per tile (the two-launch form executes seven and streams
- * Q / K / V / dO twice).  A workgroup owns a block of keys and keeps dK / dV in accumulators while it sweeps the queries;
- * dQ is summed across the key blocks of a (batch, head) by an ordered hand-off through `workspace` (fixed order per query
- * tile: bitwise reproducible, no float atomics).  `workspace` (256-byte aligned, lc2is_attention_bwd_fused_workspace_bytes;
- * 0 = this shape is not taken: more than 32 key blocks per (batch, head) or a hand-off buffer of 2 GiB and more — use
- * lc2is_attention_bwd) must not be shared by launches that may run concurrently.  No dropout form.
- * lc2is_attention_bwd_fused_status: synchronises `stream` and returns 0 when every hand-off of the last launch on
- * `workspace` completed (a hand-off that times out sets an error word instead of hanging).
- * replaces: autograd of the attention cores above (reference engine.py:100 loss.backward(); call sites
- *   model/encoder.py:29-30, model/decoder.py:9-21). */
-int lc2is_attention_delta(const void* O, int ldo, const void* dO, int lddo, float* delta, int B, int H, int Sq, int D,
-                          lc2is_stream_t stream);
-size_t lc2is_attention_bwd_fused_workspace_bytes(int B, int H, int Sq, int Sk, int D);
-int lc2is_attention_bwd_fused(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const void* O,
-                              int ldo, const void* dO, int lddo, void* dQ, int lddq, void* dK, int lddk, void* dV,
-                              int lddv, const float* lse2, float* delta, const float* kbias, int B, int H, int Sq,
-                              int Sk, int D, float scale, int causal, void* workspace, size_t workspace_bytes,
-                              lc2is_stream_t stream);
-int lc2is_attention_bwd_fused_status(const void* workspace, lc2is_stream_t stream);
-
 /* The same two operators with dropout on the attention probabilities (training mode of torch's
  * multi_head_attention_forward, dropout_p = the layer's `dropout`: torch:nn/functional.py:6206, reached from
  * PromptLayer model/decoder.py:24-28, the SR layers model/hierarchical.py:174-225 / model/decoder.py:113-134 and

@@ -390,14 +390,11 @@ int launch_attn_fwd_nq(const AttnFwdArgs& a, hipStream_t stream) {
   return lc2is_check_launch();
 }
 
-// 64 queries per wave (NQ = 2) where it measured faster (see the table in DESIGN.md); LC2IS_ATTN_FWD_NQ=1|2 forces one form (A/B)
+// NQ = 1 (32 queries per wave) is the one instantiation the library carries.  NQ = 2 (64 queries per wave: built and parity-green in
+// round 4, 161 vs 156 us at the ViT shape, 2 waves/SIMD instead of 3 — tools/probes/README.md, profiles/r04_attn_fwd_nq_ab.txt)
+// stays a template parameter of the kernel source only.
 template <int D, bool DROP>
 int launch_attn_fwd(const AttnFwdArgs& a, hipStream_t stream) {
-  static const int forced = [] { const char* e = getenv("LC2IS_ATTN_FWD_NQ"); return e ? atoi(e) : 0; }();
-  const int nq = forced == 1 || forced == 2 ? forced : 1;
-  if constexpr (D <= 96) {
-    if (nq == 2) return launch_attn_fwd_nq<D, DROP, 2>(a, stream);
-  }
   return launch_attn_fwd_nq<D, DROP, 1>(a, stream);
 }
 

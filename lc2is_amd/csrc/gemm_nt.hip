@@ -801,114 +801,12 @@ __global__ __launch_bounds__(512) void gemm_nt_w384_kernel(GemmNtArgs p) {
   }
 }
 
-// ---- persistent form with counted waits across the tile seam (cfg 13) ------------------------------------------------------
-// As cfg 11, but the barrier that publishes the next tile's prefetched first stage no longer drains the epilogue's stores: gfx9
-// retires loads and stores of a wave in order through ONE counter, so with the first-stage DMAs issued BEFORE the epilogue and
-// exactly S stores after them (the RC epilogue: 16 per bf16 output tensor, no branch around any of them), `s_waitcnt vmcnt(S)`
-// means "the DMAs have landed" while the stores are still in flight.  They drain under the first K step of the next tile (the
-// second stage's DMA, issued behind them, is awaited with vmcnt(0) a full K step later).  bf16 outputs only (no fp32 residual).
-template <int ACT>
-__global__ __launch_bounds__(512) void gemm_nt_persist2_kernel(GemmNtArgs p, int ntiles) {
-  constexpr int BM = 256, BN = 256, WAVES_N = 4, BK = 64;
-  constexpr int WM = 128, WN = 64, TM = 8, TN = 4;
-  constexpr int A_PIECES = 4, W_PIECES = 4;
-  constexpr int STAGE = (BM + BN) * 128;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int lane0 = threadIdx.x & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wid / WAVES_N, wn = wid % WAVES_N;
-  const int ntn = (p.N + BN - 1) / BN;
-  const unsigned a_bytes = (unsigned)p.M * (unsigned)p.lda * 2u, w_bytes = (unsigned)p.N * (unsigned)p.ldw * 2u;
-  const int nk = p.K / BK;
-  constexpr bool kAuxOut = ACT == LC2IS_ACT_QUICK_GELU || ACT == LC2IS_ACT_RELU || ACT == LC2IS_ACT_QUICK_GELU_GRAD ||
-                           ACT == LC2IS_ACT_GELU_ERF;
-  constexpr bool kAuxIn = ACT == LC2IS_ACT_DQUICK_GELU || ACT == LC2IS_ACT_DRELU || ACT == LC2IS_ACT_MUL_AUX || ACT == LC2IS_ACT_DGELU_ERF;
-  // stores a wave issues BEHIND the next tile's first-stage DMAs (RC epilogue; block-uniform): all 16 per output tensor when the
-  // DMAs go out after the bias loads, the second row group's 8 when they go out after that group's saved-tensor loads
-  const int nstores = ((p.out_bf16 ? 1 : 0) + ((kAuxOut && p.aux_out) ? 1 : 0)) * (kAuxIn ? 8 : 16);
-
-  auto first_stage = [&](int t, int lane) {
-    const int tile = xcd_remap(t, ntiles);
-    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
-    const int lrow = lane >> 3, lch = (lane & 7) ^ (lane >> 3);
-    int a_goff[A_PIECES], w_goff[W_PIECES];
-#pragma unroll
-    for (int j = 0; j < A_PIECES; ++j) a_goff[j] = ((m0 + 8 * (wid * A_PIECES + j) + lrow) * p.lda + lch * 8) * 2;
-#pragma unroll
-    for (int j = 0; j < W_PIECES; ++j) w_goff[j] = ((n0 + 8 * (wid * W_PIECES + j) + lrow) * p.ldw + lch * 8) * 2;
-    dma_stage<BM, A_PIECES, W_PIECES>(p.A, a_bytes, p.W, w_bytes, smem, wid, a_goff, w_goff, 0);
-  };
-  auto publish = [&](int outstanding_stores) {   // the wave's DMAs have landed (stores issued behind them may still fly); then all waves'
-    if (outstanding_stores == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (outstanding_stores == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if (outstanding_stores == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  };
-
-  int t = blockIdx.x;
-  if (t >= ntiles) return;
-  first_stage(t, lane0);
-  int behind = 0;   // stores issued behind the pending first-stage DMAs
-  for (;;) {
-    int lane = lane0;
-    asm volatile("" : "+v"(lane));
-    const int tile = xcd_remap(t, ntiles);
-    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
-    const int lrow = lane >> 3, lch = (lane & 7) ^ (lane >> 3);
-    int a_goff[A_PIECES], w_goff[W_PIECES];
-#pragma unroll
-    for (int j = 0; j < A_PIECES; ++j) a_goff[j] = ((m0 + 8 * (wid * A_PIECES + j) + lrow) * p.lda + lch * 8) * 2;
-#pragma unroll
-    for (int j = 0; j < W_PIECES; ++j) w_goff[j] = ((n0 + 8 * (wid * W_PIECES + j) + lrow) * p.ldw + lch * 8) * 2;
-    const int frow = lane & 15, g = lane >> 4, sw = lane & 7;
-    const int x_frag = (wm * WM + frow) * 128;
-    const int w_frag = BM * 128 + (wn * WN + frow) * 128;
-    const int kc_off0 = ((0 + g) ^ sw) << 4, kc_off1 = ((4 + g) ^ sw) << 4;
-
-    publish(behind);   // K tile 0 of this output tile has landed; the previous epilogue's patches (stage 1) are idle
-    f32x4_t acc[TN][TM];
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-      for (int j = 0; j < TM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    for (int kt = 0; kt < nk; ++kt) {
-      const char* cur = smem + (kt & 1) * STAGE;
-      if (kt + 1 < nk)
-        dma_stage<BM, A_PIECES, W_PIECES>(p.A, a_bytes, p.W, w_bytes, smem + ((kt + 1) & 1) * STAGE, wid, a_goff, w_goff,
-                                          (kt + 1) * BK * 2);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int ko = ks ? kc_off1 : kc_off0;
-        bf16x8_t xf[TM], wf[TN];
-#pragma unroll
-        for (int j = 0; j < TM; ++j) xf[j] = *(const bf16x8_t*)(cur + x_frag + j * 16 * 128 + ko);
-#pragma unroll
-        for (int i = 0; i < TN; ++i) wf[i] = *(const bf16x8_t*)(cur + w_frag + i * 16 * 128 + ko);
-#pragma unroll
-        for (int i = 0; i < TN; ++i)
-#pragma unroll
-          for (int j = 0; j < TM; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-      }
-      publish(0);   // everything older — the previous tile's stores included — has retired; the next K tile is published
-    }
-    t += gridDim.x;
-    const bool more = t < ntiles;
-    int lane_e = lane0;
-    asm volatile("" : "+v"(lane_e));
-    // stage 0 is free (every wave is past the last K step's barrier): the next tile's first stage is requested from inside the
-    // epilogue, behind its last global load; patches in stage 1 (+ 9 KiB)
-    gemm_epilogue_lds_act<ACT, TM, TN, WM, WN, true>(p, acc, m0, n0, wm, wn, lane_e, wid, smem + STAGE,
-                                                     [&]() { if (more) first_stage(t, lane_e); });
-    behind = nstores;
-    if (!more) break;
-  }
-}
-
 // ---- persistent form with the two wave groups in PING-PONG (cfg 15) ------------------------------------------------------------
-// Same tile algebra, epilogue and seam as cfg 13 (bitwise equal to cfg 4), but the K step is no longer executed by all eight
+// Tile algebra and epilogue of cfg 4 (bitwise equal to it).  The seam between two tiles of a block: gfx9 retires loads and stores
+// of a wave in order through ONE counter, so with the next tile's first-stage DMAs issued from inside the epilogue and exactly S
+// stores behind them (the RC epilogue: 16 per bf16 output tensor, no branch around any of them), `s_waitcnt vmcnt(S)` means "the
+// DMAs have landed" while the stores are still in flight (round 2's cfg 13, archived under tools/probes/gemm_nt_persist2/, was the
+// lockstep form of this kernel).  bf16 outputs only (no fp32 residual).  The K step is no longer executed by all eight
 // waves in lockstep ("everybody issues DMA pieces — no MFMA in flight for ~960 cycles —, everybody runs 64 MFMAs on a matrix pipe
 // shared with its SIMD partner, everybody waits at the barrier": profiles/r03_gemm_step_stamps.txt, 3440 cycles per K step for
 // 2048 cycles of matrix pipe).  The two groups of four waves (wm = 0 / 1; the partners on a SIMD are waves w and w + 4) run HALF
@@ -1179,22 +1077,6 @@ int launch_rows(const GemmNtArgs& a, hipStream_t stream) {
   return lc2is_check_launch();
 }
 
-template <int ACT>
-int launch_persist2_act(const GemmNtArgs& a, hipStream_t stream) {
-  constexpr int LDS = (256 + 256) * 128 + 8 * 64 * 144;
-  static DevOnce attr_set;
-  if (attr_set.need()) {
-    if (hipFuncSetAttribute((const void*)gemm_nt_persist2_kernel<ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
-        hipSuccess)
-      return LC2IS_ERR_LAUNCH;
-    attr_set.done();
-  }
-  const int ntiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
-  const int grid = ntiles < lc2is_ncu() ? ntiles : lc2is_ncu();   // one block per CU of the budget (common.h)
-  hipLaunchKernelGGL(gemm_nt_persist2_kernel<ACT>, dim3(grid), dim3(512), LDS, stream, a, ntiles);
-  return lc2is_check_launch();
-}
-
 // the counted-wait persistent kernel takes bf16-output problems through the staged epilogue only (see the kernel's comment)
 bool persist2_ok(const GemmNtArgs& a) {
   const double lim = 2147483648.0;
@@ -1208,16 +1090,6 @@ int launch_pp(const GemmNtArgs& a, hipStream_t stream) {
     case LC2IS_ACT_QUICK_GELU: return launch_pp_act<LC2IS_ACT_QUICK_GELU>(a, stream);
     case LC2IS_ACT_DQUICK_GELU: return launch_pp_act<LC2IS_ACT_DQUICK_GELU>(a, stream);
     case LC2IS_ACT_NONE: return launch_pp_act<LC2IS_ACT_NONE>(a, stream);
-    default: return LC2IS_ERR_UNSUPPORTED;
-  }
-}
-
-int launch_persist2(const GemmNtArgs& a, hipStream_t stream) {
-  if (!persist2_ok(a)) return LC2IS_ERR_UNSUPPORTED;
-  switch (a.act) {
-    case LC2IS_ACT_QUICK_GELU: return launch_persist2_act<LC2IS_ACT_QUICK_GELU>(a, stream);
-    case LC2IS_ACT_DQUICK_GELU: return launch_persist2_act<LC2IS_ACT_DQUICK_GELU>(a, stream);
-    case LC2IS_ACT_NONE: return launch_persist2_act<LC2IS_ACT_NONE>(a, stream);
     default: return LC2IS_ERR_UNSUPPORTED;
   }
 }
@@ -1255,7 +1127,6 @@ int launch_by_cfg(const GemmNtArgs& a_in, int cfg, hipStream_t stream) {
         case LC2IS_ACT_NONE: return launch_dma<128, 128, 2, 2, LC2IS_ACT_NONE>(a, stream);
         default: return launch_dma<128, 128, 2, 2>(a, stream);
       }
-    case 13: return launch_persist2(a, stream);
     case 15: return launch_pp(a, stream);
     case 16: return launch_w384(a, stream);
     case 17: return launch_rows(a, stream);
@@ -1336,7 +1207,7 @@ extern "C" int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw
     // (B x 1025 tokens: 32 rows, i.e. one more row of N / 256 tiles) are peeled off into a small-tile launch when that saves a
     // whole tile time: fc1 / dfc2 at M = 32 800 walk 1548 tiles = 6 rounds + 12 tiles, 1536 = exactly 6 without the 32 rows.
     static const bool peel = !(getenv("LC2IS_GEMM_PERSIST_PEEL") && atoi(getenv("LC2IS_GEMM_PERSIST_PEEL")) == 0);
-    static const int pcfg = (getenv("LC2IS_GEMM_PP") && atoi(getenv("LC2IS_GEMM_PP")) == 0) ? 13 : 15;   // cfg 15 = the wave groups in ping-pong (round 4: 966 -> 975 img/s); LC2IS_GEMM_PP=0: cfg 13
+    constexpr int pcfg = 15;   // the wave groups in ping-pong (round 4: 966 -> 975 img/s against cfg 13, the lockstep persistent form — now tools/probes/gemm_nt_persist2/)
     const int r = M % 256;
     const long tiles_all = (long)((M + 255) / 256) * (N / 256), tiles_main = (long)(M / 256) * (N / 256);
     if (peel && r > 0 && r <= 64 && M > 256 && lc2is_rounds(tiles_main) < lc2is_rounds(tiles_all)) {

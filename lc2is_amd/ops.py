@@ -35,11 +35,6 @@ _ARGTYPES = {
     "lc2is_attention_fwd": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "lc2is_attention_bwd": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P,
                             _I, _I, _I, _I, _I, _F, _I, _P],
-    "lc2is_attention_delta": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P],
-    "lc2is_attention_bwd_fused_workspace_bytes": [_I, _I, _I, _I, _I],
-    "lc2is_attention_bwd_fused": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P,
-                                  _I, _I, _I, _I, _I, _F, _I, _P, _Z, _P],
-    "lc2is_attention_bwd_fused_status": [_P, _P],
     "lc2is_attention_fwd_dropout": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _I, _F, _U64, _P],
     "lc2is_attention_bwd_dropout": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P,
                                     _I, _I, _I, _I, _I, _F, _I, _F, _U64, _P],
@@ -457,28 +452,9 @@ def attention_bwd(q, k, v, o, do, lse2, B: int, H: int, Sq: int, Sk: int, D: int
     if dropout_p > 0.0:
         rc = _fn("lc2is_attention_bwd_dropout")(*args, float(dropout_p), int(seed), _stream())
     else:
-        # LC2IS_ATTN_BWD_FUSED=1: the one-kernel five-product form with the ordered dQ hand-off (default: the two-launch form); its
-        # workspace belongs to this call's stream (the caching allocator recycles it in stream order)
-        ws_bytes = _fn("lc2is_attention_bwd_fused_workspace_bytes")(B, H, Sq, Sk, D) if _ATTN_BWD_FUSED else 0
-        if ws_bytes:
-            global _last_fused_ws
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-            _last_fused_ws = ws
-            rc = _fn("lc2is_attention_bwd_fused")(*args, _ptr(ws), ws_bytes, _stream())
-        else:
-            rc = _fn("lc2is_attention_bwd")(*args, _stream())
+        rc = _fn("lc2is_attention_bwd")(*args, _stream())
     _lib.check(rc, f"attention_bwd B={B} H={H} Sq={Sq} Sk={Sk} D={D}")
     return dq, dk, dv
-
-
-_ATTN_BWD_FUSED = os.environ.get("LC2IS_ATTN_BWD_FUSED", "0") != "0"   # opt-in: measured slower than the two-launch form
-_last_fused_ws = None
-
-
-def attention_bwd_status() -> None:
-    """Synchronise and raise if a dQ hand-off of the most recent fused attention backward timed out (tests / debugging)."""
-    if _last_fused_ws is not None:
-        _lib.check(_fn("lc2is_attention_bwd_fused_status")(_ptr(_last_fused_ws), _stream()), "attention_bwd hand-off")
 
 
 def dropout_rows_f32(x: torch.Tensor, p: float, seed: int, *, resid: torch.Tensor | None = None,

@@ -105,34 +105,6 @@ def test_gemm_nt_activation_and_backward_epilogue(dev, act, cfg):
     assert _rel(dz.float(), ref) < 5e-3
 
 
-@pytest.mark.parametrize("M,N,K", [(2050, 768, 768), (300, 200, 128), (66000, 512, 64), (70, 64, 64)])
-def test_gemm_nt_persistent_counted_waits_is_bitwise_equal(dev, M, N, K):
-    """tile_cfg 13 — the persistent 256x256 kernel whose tile seam waits with `s_waitcnt vmcnt(#stores)` instead of draining —
-    against tile_cfg 4 (same tile algebra): plain + bias, quick_gelu with the saved pre-activation, the quick_gelu derivative
-    epilogue; ragged M and N, more tiles than CUs (several tiles per block: 66000 x 512 = 516 tiles), a single tile.  An
-    under-counted wait would read a K stage before its DMA landed."""
-    from lc2is_amd import ops
-    g = torch.Generator(device="cpu").manual_seed(M + N)
-    a = _bf(torch.randn(M, K, generator=g)).to(dev)
-    w = _bf(torch.randn(N, K, generator=g) * 0.1).to(dev)
-    bias = torch.randn(N, generator=g).to(dev)
-    saved = _bf(torch.randn(M, N, generator=g)).to(dev)
-    for rep in range(2):   # (twice: the second run starts on warm caches, a different DMA timing)
-        o4, _, _ = ops.gemm_nt(a, w, bias, tile_cfg=4)
-        o13, _, _ = ops.gemm_nt(a, w, bias, tile_cfg=13)
-        assert torch.equal(o4, o13)
-        o4, _, z4 = ops.gemm_nt(a, w, bias, act=ops.ACT_QUICK_GELU, aux_out=True, tile_cfg=4)
-        o13, _, z13 = ops.gemm_nt(a, w, bias, act=ops.ACT_QUICK_GELU, aux_out=True, tile_cfg=13)
-        assert torch.equal(o4, o13) and torch.equal(z4, z13)
-        d4, _, _ = ops.gemm_nt(a, w, None, act=ops.ACT_DQUICK_GELU, aux_in=saved, tile_cfg=4)
-        d13, _, _ = ops.gemm_nt(a, w, None, act=ops.ACT_DQUICK_GELU, aux_in=saved, tile_cfg=13)
-        assert torch.equal(d4, d13)
-    ref = a.double() @ w.double().T + bias.double()
-    assert _rel(ops.gemm_nt(a, w, bias, tile_cfg=13)[0].float(), ref) < 4e-3
-    with pytest.raises(RuntimeError):   # fp32 / residual outputs are not this kernel's
-        ops.gemm_nt(a, w, bias, out_bf16=None, out_f32=True, tile_cfg=13)
-
-
 @pytest.mark.parametrize("M,N,K", [(2050, 768, 768), (300, 200, 128), (66000, 512, 64), (70, 64, 64), (32800, 768, 192),
                                    (33000, 512, 320), (4100, 1024, 3072)])
 def test_gemm_nt_ping_pong_is_bitwise_equal(dev, M, N, K):
