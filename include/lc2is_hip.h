@@ -33,6 +33,8 @@ extern "C" {
 #define LC2IS_ACT_MUL_AUX 6     /* backward: acc * aux_in (aux_in = the derivative saved by code 5)     */
 #define LC2IS_ACT_GELU_ERF 7    /* exact GELU 0.5x(1+erf(x/sqrt2)), hf:activations.py "gelu" (Swin MLP) */
 #define LC2IS_ACT_DGELU_ERF 8   /* backward: acc * gelu'(aux_in)                                         */
+#define LC2IS_ACT_ADD_AUX 9     /* acc + bias + aux_in: the residual add of a bf16 residual stream (`x + out_proj(..)`,
+                                   `x + fc2(..)` of hf CLIPEncoderLayer.forward:362-383), fp32 add, one rounding */
 
 #define LC2IS_INTERP_BICUBIC 0  /* F.interpolate(mode="bicubic", align_corners=False), A = -0.75, border clamp */
 #define LC2IS_INTERP_BILINEAR 1 /* F.interpolate(mode="bilinear", align_corners=False)                          */
@@ -247,12 +249,16 @@ int lc2is_vit_embed_bwd(const float* dx, int ldx, float* dpos, float* dcls, void
  * backward (dtok via fp32 atomics into a caller-zeroed/running [vocab,C] gradient). */
 int lc2is_text_embed_fwd(const int64_t* ids, const float* tok, const float* pos, float* x, int ldx, int B,
                          int L, int C, int vocab, lc2is_stream_t stream);
+/* dtok (zeros or the running gradient) += per-token sums in row order, no atomics: bitwise reproducible */
 int lc2is_text_embed_bwd(const int64_t* ids, const float* dx, int ldx, float* dtok, float* dpos, int B, int L,
                          int C, int vocab, int accumulate, lc2is_stream_t stream);
 /* dst[b, dst_off+s, :] = src[b, src_off+s, :], s < n (fp32 rows of C, optional bf16 copy): drops / re-inserts
  * the CLS token (`last_hidden_state[:, 1:, :]`, model/encoder.py:30). */
 int lc2is_rows_copy_f32(const float* src, int S_src, int src_off, float* dst_f32, void* dst_bf16, int S_dst,
                         int dst_off, int B, int n, int C, lc2is_stream_t stream);
+/* the same from bf16 rows (a bf16 residual stream): widened into dst_f32 and / or copied into dst_bf16 */
+int lc2is_rows_copy_bf16(const void* src, int S_src, int src_off, float* dst_f32, void* dst_bf16, int S_dst,
+                         int dst_off, int B, int n, int C, lc2is_stream_t stream);
 
 /* Fused optimizer step over the flat fp32 parameter arena (n % 4 == 0).  g is multiplied by grad_scale
  * (1/world_size for DP).  SGD: torch.optim.SGD semantics (momentum_buf may be NULL); AdamW: torch.optim.AdamW.

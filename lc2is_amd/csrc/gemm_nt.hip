@@ -38,7 +38,7 @@ __device__ __forceinline__ void gemm_epilogue_act(const GemmNtArgs& p, f32x4_t (
     // every load of this column of sub-tiles is issued before its first store: the outputs may alias the inputs
     // (in-place residual), so the compiler will not hoist them itself and each sub-tile would pay a full load latency
     constexpr bool kAux = act == LC2IS_ACT_DQUICK_GELU || act == LC2IS_ACT_DRELU || act == LC2IS_ACT_MUL_AUX ||
-                          act == LC2IS_ACT_DGELU_ERF;
+                          act == LC2IS_ACT_DGELU_ERF || act == LC2IS_ACT_ADD_AUX;
     constexpr int PF = TM < 4 ? TM : 4;   // sub-tiles prefetched together (more would spill beside 128 accumulators)
 #pragma unroll
     for (int j0 = 0; j0 < TM; j0 += PF) {
@@ -89,6 +89,8 @@ __device__ __forceinline__ void gemm_epilogue_act(const GemmNtArgs& p, f32x4_t (
         for (int r = 0; r < 4; ++r) {
           if (act == LC2IS_ACT_MUL_AUX) {
             v[r] *= z[r];
+          } else if (act == LC2IS_ACT_ADD_AUX) {
+            v[r] += z[r];
           } else if (act == LC2IS_ACT_DRELU) {
             v[r] = z[r] > 0.f ? v[r] : 0.f;
           } else if (act == LC2IS_ACT_DGELU_ERF) {
@@ -120,6 +122,7 @@ __device__ __forceinline__ void gemm_epilogue_act(const GemmNtArgs& p, f32x4_t (
     case LC2IS_ACT_MUL_AUX: CALL(LC2IS_ACT_MUL_AUX); break;                   \
     case LC2IS_ACT_GELU_ERF: CALL(LC2IS_ACT_GELU_ERF); break;                 \
     case LC2IS_ACT_DGELU_ERF: CALL(LC2IS_ACT_DGELU_ERF); break;               \
+    case LC2IS_ACT_ADD_AUX: CALL(LC2IS_ACT_ADD_AUX); break;                   \
     default: CALL(LC2IS_ACT_NONE); break;                                     \
   }
 
@@ -159,7 +162,7 @@ __device__ __forceinline__ void gemm_epilogue_lds_act(const GemmNtArgs& p, f32x4
   const bool col_ok = (nw + sch * 8) < p.N;
 
   constexpr bool has_aux = act == LC2IS_ACT_DQUICK_GELU || act == LC2IS_ACT_DRELU || act == LC2IS_ACT_MUL_AUX ||
-                           act == LC2IS_ACT_DGELU_ERF;
+                           act == LC2IS_ACT_DGELU_ERF || act == LC2IS_ACT_ADD_AUX;
   f32x4_t bvs[TN];   // bias of the wave's columns, requested once per tile
 #pragma unroll
   for (int i = 0; i < TN; ++i) {
@@ -216,6 +219,8 @@ __device__ __forceinline__ void gemm_epilogue_lds_act(const GemmNtArgs& p, f32x4
           for (int r = 0; r < 4; ++r) {
             if (act == LC2IS_ACT_MUL_AUX) {
               v[r] *= z[r];
+            } else if (act == LC2IS_ACT_ADD_AUX) {
+              v[r] += z[r];
             } else if (act == LC2IS_ACT_DGELU_ERF) {
               v[r] *= dgelu_erf(z[r]);
             } else if (act == LC2IS_ACT_DRELU) {
@@ -643,6 +648,9 @@ __global__ __launch_bounds__(64) void gemm_nt_rows_kernel(GemmNtArgs p) {
 // the epilogue's patches overlay them.  Same K order as every other tile shape: bitwise equal to tile_cfg 4.
 // EPI = -2: fp32-only output (bias + fp32 residual -> fp32), through LDS in whole 384-byte row segments, 32 rows at a time;
 // EPI = 0: bf16-only output (bias, no activation: the dgrads that feed LayerNorm backward and the attention backward), 192-byte segments.
+// EPI = 1 (round 5): bf16 output = bf16(acc + bias + aux_in), aux_in the bf16 RESIDUAL STREAM (LC2IS_ACT_ADD_AUX: out-proj, fc2):
+//   the 32 x 96 residual rows come in as whole 192-byte segments (the flush mapping), cross the wave's patch into the MFMA layout,
+//   are added in fp32 and leave through the same patch; the next row group's segments are requested before the current group's math.
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_nt_w384_kernel(GemmNtArgs p) {
   constexpr int BM = 256, BN = 384, WAVES_N = 4, NWAVE = 8, BK = 64;
@@ -714,7 +722,57 @@ __global__ __launch_bounds__(512) void gemm_nt_w384_kernel(GemmNtArgs p) {
     bvs[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     if (p.bias && n < p.N) bvs[i] = *(const f32x4_t*)(p.bias + n);
   }
-  if constexpr (EPI == 0) {
+  if constexpr (EPI == 1) {
+    // ---- bf16 epilogue with the bf16 residual stream: out = bf16(acc + bias + aux_in), 16 rows x 96 columns of the wave at a time.
+    // The residual rows arrive as whole 192-byte segments (flush mapping: 16 rows x 12 sixteen-byte chunks = 3 wave instructions),
+    // cross the wave's patch into the MFMA layout, are added in fp32, and the sums leave through the same patch.  The next 16 rows'
+    // segments are requested before the current rows' arithmetic (12 registers in flight; a 32-row pipeline spilled).
+    constexpr int PITCHB = WN * 2 + 16;   // 208 B
+    char* patchb = smem + wid * (16 * PITCHB);
+    const int nwb = n0 + wn * WN;
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(p.out_bf16, (unsigned)p.M * (unsigned)p.ldo * 2u);
+    const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.aux_in, (unsigned)p.M * (unsigned)p.ldx * 2u);
+    constexpr int OOBB = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < TN; ++i)   // bias into the accumulators up front: its 24 registers are free for the epilogue
+#pragma unroll
+      for (int j = 0; j < TM; ++j) acc[i][j] += bvs[i];
+    int xoff[3], ooff[3], poff[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int e = k * 64 + lane, row = e / 12, ch = e % 12, col = nwb + ch * 8;
+      const bool ok = col < p.N;
+      xoff[k] = ok ? ((m0 + wm * WM + row) * p.ldx + col) * 2 : OOBB;   // rows >= M fall outside num_records: zeros / dropped
+      ooff[k] = ok ? ((m0 + wm * WM + row) * p.ldo + col) * 2 : OOBB;
+      poff[k] = row * PITCHB + ch * 16;
+    }
+    const int xstep = 16 * p.ldx * 2, ostep = 16 * p.ldo * 2;
+    i32x4_t rx[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rx[k] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xoff[k], 0, 0);
+#pragma unroll
+    for (int h = 0; h < TM; ++h) {
+      if (m0 + wm * WM + h * 16 >= p.M) break;   // wave-uniform
+#pragma unroll
+      for (int k = 0; k < 3; ++k) *(i32x4_t*)(patchb + poff[k]) = rx[k];
+      if (h + 1 < TM) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) rx[k] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xoff[k], (h + 1) * xstep, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {   // (the lane that reads a patch word is the lane that overwrites it: in-order LDS traffic of one wave)
+        char* w = patchb + frow * PITCHB + (i * 16 + g * 4) * 2;
+        const i32x2_t zk = *(const i32x2_t*)w;
+        f32x4_t v = acc[i][h];
+        v[0] += bf16_to_f32((bf16_t)(zk[0] & 0xffff)); v[1] += bf16_to_f32((bf16_t)((unsigned)zk[0] >> 16));
+        v[2] += bf16_to_f32((bf16_t)(zk[1] & 0xffff)); v[3] += bf16_to_f32((bf16_t)((unsigned)zk[1] >> 16));
+        *(i32x2_t*)w = i32x2_t{(int)pack_bf16x2(v[0], v[1]), (int)pack_bf16x2(v[2], v[3])};
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        __builtin_amdgcn_raw_buffer_store_b128(*(const i32x4_t*)(patchb + poff[k]), rsB, ooff[k], h * ostep, 0);   // write-back: LayerNorm reads the stream next
+    }
+  } else if constexpr (EPI == 0) {
     // ---- bf16 epilogue: out = bf16(acc + bias), 32 rows x 96 columns of the wave at a time through its LDS patch ----
     constexpr int PITCHB = WN * 2 + 16;   // 208 B
     char* patchb = smem + wid * (32 * PITCHB);
@@ -797,7 +855,7 @@ __global__ __launch_bounds__(512) void gemm_nt_w384_kernel(GemmNtArgs p) {
     q.M = p.M + p.tail_rows;
     const int nfn = p.N / 16, njobs = nfn * ((p.tail_rows + 15) / 16);
     for (int job = wid * (int)gridDim.x + (int)blockIdx.x; job < njobs; job += 8 * (int)gridDim.x)
-      rows_fragment<16, LC2IS_ACT_NONE>(q, (job % nfn) * 16, p.M + (job / nfn) * 16, lane);
+      rows_fragment<16, EPI == 1 ? LC2IS_ACT_ADD_AUX : LC2IS_ACT_NONE>(q, (job % nfn) * 16, p.M + (job / nfn) * 16, lane);
   }
 }
 
@@ -849,8 +907,11 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmNtArgs p, int ntile
   const int nk = p.K / BK;
   constexpr bool kAuxOut = ACT == LC2IS_ACT_QUICK_GELU || ACT == LC2IS_ACT_RELU || ACT == LC2IS_ACT_QUICK_GELU_GRAD ||
                            ACT == LC2IS_ACT_GELU_ERF;
-  constexpr bool kAuxIn = ACT == LC2IS_ACT_DQUICK_GELU || ACT == LC2IS_ACT_DRELU || ACT == LC2IS_ACT_MUL_AUX || ACT == LC2IS_ACT_DGELU_ERF;
-  const int nstores = ((p.out_bf16 ? 1 : 0) + ((kAuxOut && p.aux_out) ? 1 : 0)) * (kAuxIn ? 8 : 16);   // (see cfg 13)
+  constexpr bool kAuxIn = ACT == LC2IS_ACT_DQUICK_GELU || ACT == LC2IS_ACT_DRELU || ACT == LC2IS_ACT_MUL_AUX || ACT == LC2IS_ACT_DGELU_ERF ||
+                          ACT == LC2IS_ACT_ADD_AUX;
+  // stores a wave issues BEHIND the next tile's first-stage DMAs (RC epilogue; block-uniform): all 16 per output tensor when the
+  // DMAs go out after the bias loads, the second row group's 8 when they go out after that group's saved-tensor loads
+  const int nstores = ((p.out_bf16 ? 1 : 0) + ((kAuxOut && p.aux_out) ? 1 : 0)) * (kAuxIn ? 8 : 16);
   const unsigned smem_a = (unsigned)(size_t)LDS_PTR(smem);
 
   int issued = 0;                    // DMA pieces + counted stores this wave has issued so far
@@ -1046,7 +1107,9 @@ bool w384_f32_ok(const GemmNtArgs& a) {
          (double)a.M * a.ldf * 4.0 < 2147483648.0 && (!a.resid || (double)a.M * a.ldr * 4.0 < 2147483648.0);
 }
 bool w384_bf16_ok(const GemmNtArgs& a) {
-  return a.N % 384 == 0 && a.act == LC2IS_ACT_NONE && a.out_bf16 && !a.out_f32 && !a.resid && !a.aux_out && !a.aux_in &&
+  const bool plain = a.act == LC2IS_ACT_NONE && !a.aux_in;
+  const bool resid = a.act == LC2IS_ACT_ADD_AUX && a.aux_in && a.ldx % 8 == 0 && (double)a.M * a.ldx * 2.0 < 2147483648.0;   // bf16 residual stream
+  return a.N % 384 == 0 && (plain || resid) && a.out_bf16 && !a.out_f32 && !a.resid && !a.aux_out &&
          a.ldo % 8 == 0 && (double)a.M * a.ldo * 2.0 < 2147483648.0;
 }
 
@@ -1066,7 +1129,7 @@ int launch_w384_epi(const GemmNtArgs& a, hipStream_t stream) {
 
 int launch_w384(const GemmNtArgs& a, hipStream_t stream) {
   if (w384_f32_ok(a)) return launch_w384_epi<-2>(a, stream);
-  if (w384_bf16_ok(a)) return launch_w384_epi<0>(a, stream);
+  if (w384_bf16_ok(a)) return a.act == LC2IS_ACT_ADD_AUX ? launch_w384_epi<1>(a, stream) : launch_w384_epi<0>(a, stream);
   return LC2IS_ERR_UNSUPPORTED;
 }
 
@@ -1090,6 +1153,7 @@ int launch_pp(const GemmNtArgs& a, hipStream_t stream) {
     case LC2IS_ACT_QUICK_GELU: return launch_pp_act<LC2IS_ACT_QUICK_GELU>(a, stream);
     case LC2IS_ACT_DQUICK_GELU: return launch_pp_act<LC2IS_ACT_DQUICK_GELU>(a, stream);
     case LC2IS_ACT_NONE: return launch_pp_act<LC2IS_ACT_NONE>(a, stream);
+    case LC2IS_ACT_ADD_AUX: return launch_pp_act<LC2IS_ACT_ADD_AUX>(a, stream);
     default: return LC2IS_ERR_UNSUPPORTED;
   }
 }
@@ -1114,6 +1178,7 @@ int launch_by_cfg(const GemmNtArgs& a_in, int cfg, hipStream_t stream) {
         case LC2IS_ACT_GELU_ERF: return launch_dma<256, 256, 2, 4, LC2IS_ACT_GELU_ERF>(a, stream);
         case LC2IS_ACT_DGELU_ERF: return launch_dma<256, 256, 2, 4, LC2IS_ACT_DGELU_ERF>(a, stream);
         case LC2IS_ACT_NONE: return launch_dma<256, 256, 2, 4, LC2IS_ACT_NONE>(a, stream);
+        case LC2IS_ACT_ADD_AUX: return launch_dma<256, 256, 2, 4, LC2IS_ACT_ADD_AUX>(a, stream);
         default: return launch_dma<256, 256, 2, 4>(a, stream);   // codes 5 / 6 (experiments) keep the run-time switch
       }
     case 6:
@@ -1125,6 +1190,7 @@ int launch_by_cfg(const GemmNtArgs& a_in, int cfg, hipStream_t stream) {
         case LC2IS_ACT_GELU_ERF: return launch_dma<128, 128, 2, 2, LC2IS_ACT_GELU_ERF>(a, stream);
         case LC2IS_ACT_DGELU_ERF: return launch_dma<128, 128, 2, 2, LC2IS_ACT_DGELU_ERF>(a, stream);
         case LC2IS_ACT_NONE: return launch_dma<128, 128, 2, 2, LC2IS_ACT_NONE>(a, stream);
+        case LC2IS_ACT_ADD_AUX: return launch_dma<128, 128, 2, 2, LC2IS_ACT_ADD_AUX>(a, stream);
         default: return launch_dma<128, 128, 2, 2>(a, stream);
       }
     case 15: return launch_pp(a, stream);
@@ -1149,9 +1215,10 @@ extern "C" int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw
   if ((out_bf16 && (ldo < N || ldo % 4)) || (out_f32 && (ldf < N || ldf % 4)) || (resid && (ldr < N || ldr % 4)) ||
       (aux_in && (ldx < N || ldx % 4)) || (aux_out && (ldy < N || ldy % 4)))
     return LC2IS_ERR_SHAPE;
-  if ((act == LC2IS_ACT_DQUICK_GELU || act == LC2IS_ACT_DRELU || act == LC2IS_ACT_MUL_AUX || act == LC2IS_ACT_DGELU_ERF) && !aux_in)
+  if ((act == LC2IS_ACT_DQUICK_GELU || act == LC2IS_ACT_DRELU || act == LC2IS_ACT_MUL_AUX || act == LC2IS_ACT_DGELU_ERF ||
+       act == LC2IS_ACT_ADD_AUX) && !aux_in)
     return LC2IS_ERR_NULL;
-  if (act < LC2IS_ACT_NONE || act > LC2IS_ACT_DGELU_ERF) return LC2IS_ERR_UNSUPPORTED;
+  if (act < LC2IS_ACT_NONE || act > LC2IS_ACT_ADD_AUX) return LC2IS_ERR_UNSUPPORTED;
   // 32-bit buffer offsets: operand panels (plus one tile of overhang) must stay under 2 GiB
   if ((double)(M + 256) * lda * 2.0 >= 2147483648.0 || (double)(N + 256) * ldw * 2.0 >= 2147483648.0)
     return LC2IS_ERR_UNSUPPORTED;
@@ -1194,6 +1261,7 @@ extern "C" int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw
       tail.M = M - mm;
       tail.A = a.A + (size_t)mm * lda;
       tail.out_bf16 = a.out_bf16 + (size_t)mm * ldo;
+      if (a.aux_in) tail.aux_in = a.aux_in + (size_t)mm * ldx;
       return launch_by_cfg(tail, tail_cfg, stream);
     }
   }
@@ -1202,7 +1270,7 @@ extern "C" int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw
   static const bool use_persist = !(getenv("LC2IS_GEMM_PERSIST") && atoi(getenv("LC2IS_GEMM_PERSIST")) == 0);
   static const long persist_min = getenv("LC2IS_GEMM_PERSIST_MIN") ? atol(getenv("LC2IS_GEMM_PERSIST_MIN")) : 257;   // more than one round of tiles (A/B 512 -> 257: 907 -> 915 img/s)
   if (use_persist && persist2_ok(a) && (long)((M + 255) / 256) * (N / 256) >= persist_min &&
-      (act == LC2IS_ACT_NONE || act == LC2IS_ACT_QUICK_GELU || act == LC2IS_ACT_DQUICK_GELU)) {
+      (act == LC2IS_ACT_NONE || act == LC2IS_ACT_QUICK_GELU || act == LC2IS_ACT_DQUICK_GELU || act == LC2IS_ACT_ADD_AUX)) {
     // One block per CU walks tiles t, t + 256, ...: the launch lasts ceil(tiles / 256) tile times.  The ragged last <= 64 rows
     // (B x 1025 tokens: 32 rows, i.e. one more row of N / 256 tiles) are peeled off into a small-tile launch when that saves a
     // whole tile time: fc1 / dfc2 at M = 32 800 walk 1548 tiles = 6 rounds + 12 tiles, 1536 = exactly 6 without the 32 rows.

@@ -190,25 +190,54 @@ __global__ __launch_bounds__(256) void text_embed_fwd_kernel(const int64_t* __re
   }
 }
 
-// dtok[ids[r]] += dx[r] (float atomics; dtok must be zeroed or hold the running gradient),
-// dpos[l] (+)= sum_b dx[b*L+l]
-__global__ __launch_bounds__(256) void text_embed_bwd_kernel(const int64_t* __restrict__ ids,
-                                                              const float* __restrict__ dx, int ldx,
-                                                              float* dtok, float* dpos, int B, int L, int C,
-                                                              int vocab, int accumulate) {
+// dtok[id] += sum over the rows r (in ascending order) with ids[r] == id of dx[r]  (dtok holds zeros or the running gradient);
+// dpos[l] (+)= sum_b dx[b*L+l].  NO ATOMICS (round 5; rounds 1-4 scattered with fp32 atomics, whose arrival order made the step's
+// last bits run-dependent): block r owns token row r.  It first scans ids[0..r) for an earlier occurrence of its id — if there is
+// one, the block that owns the FIRST occurrence does the work and this one leaves — then sums the rows r' >= r that carry the id
+// in row order and adds the sum to dtok[id] with a plain read-modify-write (the id has exactly one owner).  B*L is a few
+// hundred to a few thousand rows: the scans are L2-resident integer reads.
+__global__ __launch_bounds__(256) void text_embed_dtok_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dx,
+                                                               int ldx, float* dtok, int R, int C, int vocab) {
+  const int r = blockIdx.x;
+  auto clampid = [&](int64_t v) { return v < 0 ? (int64_t)0 : (v >= vocab ? (int64_t)(vocab - 1) : v); };
+  const int64_t id = clampid(ids[r]);
+  int seen = 0;
+  for (int q = threadIdx.x; q < r; q += 256) seen |= (clampid(ids[q]) == id);
+  if (__syncthreads_or(seen)) return;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float acc = 0.f;
+    for (int q = r; q < R; ++q)                 // (block-uniform condition: one scalar compare per row)
+      if (clampid(ids[q]) == id) acc += dx[(size_t)q * ldx + c];
+    dtok[(size_t)id * C + c] += acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void text_embed_bwd_kernel(const float* __restrict__ dx, int ldx, float* dpos, int B, int L,
+                                                              int C, int accumulate) {
   const int total = L * C;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
     const int c = i % C, l = i / C;
     float acc = 0.f;
-    for (int b = 0; b < B; ++b) {
-      const float v = dx[((size_t)b * L + l) * ldx + c];
-      acc += v;
-      int64_t id = ids[b * L + l];
-      if (id < 0) id = 0;
-      if (id >= vocab) id = vocab - 1;
-      atomicAdd(dtok + (size_t)id * C + c, v);
-    }
+    for (int b = 0; b < B; ++b) acc += dx[((size_t)b * L + l) * ldx + c];
     dpos[(size_t)l * C + c] = accumulate ? dpos[(size_t)l * C + c] + acc : acc;
+  }
+}
+
+// the same row copy from a bf16 source (the bf16 residual stream of round 5): widened to fp32 and / or copied as bf16
+__global__ __launch_bounds__(256) void rows_copy_bf16_kernel(const bf16_t* __restrict__ src, int S_src, int src_off,
+                                                              float* dst, bf16_t* dst_b, int S_dst, int dst_off,
+                                                              int B, int n, int C) {
+  const int C4 = C >> 2;
+  const size_t total = (size_t)B * n * C4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c4 = (int)(i % C4);
+    const int r = (int)(i / C4);
+    const int s = r % n, b = r / n;
+    const uint2 pk = *reinterpret_cast<const uint2*>(src + ((size_t)b * S_src + src_off + s) * C + 4 * c4);
+    const size_t o = ((size_t)b * S_dst + dst_off + s) * C + 4 * c4;
+    if (dst) *reinterpret_cast<float4*>(dst + o) = make_float4(bf16_to_f32((bf16_t)(pk.x & 0xffff)), bf16_to_f32((bf16_t)(pk.x >> 16)),
+                                                               bf16_to_f32((bf16_t)(pk.y & 0xffff)), bf16_to_f32((bf16_t)(pk.y >> 16)));
+    if (dst_b) *reinterpret_cast<uint2*>(dst_b + o) = pk;
   }
 }
 
@@ -375,8 +404,11 @@ extern "C" int lc2is_text_embed_bwd(const int64_t* ids, const float* dx, int ldx
   hipStream_t stream = (hipStream_t)stream_;
   if (!ids || !dx || !dtok || !dpos) return LC2IS_ERR_NULL;
   if (B <= 0 || L <= 0 || C <= 0 || vocab <= 0 || ldx < C) return LC2IS_ERR_SHAPE;
-  hipLaunchKernelGGL(text_embed_bwd_kernel, dim3(ew_grid((size_t)L * C)), dim3(256), 0, stream, ids, dx, ldx,
-                     dtok, dpos, B, L, C, vocab, accumulate);
+  hipLaunchKernelGGL(text_embed_dtok_kernel, dim3(B * L), dim3(256), 0, stream, ids, dx, ldx, dtok, B * L, C, vocab);
+  int rc = lc2is_check_launch();
+  if (rc) return rc;
+  hipLaunchKernelGGL(text_embed_bwd_kernel, dim3(ew_grid((size_t)L * C)), dim3(256), 0, stream, dx, ldx, dpos, B, L, C,
+                     accumulate);
   return lc2is_check_launch();
 }
 
@@ -389,6 +421,18 @@ extern "C" int lc2is_rows_copy_f32(const float* src, int S_src, int src_off, flo
     return LC2IS_ERR_SHAPE;
   hipLaunchKernelGGL(rows_copy_kernel, dim3(ew_grid((size_t)B * n * C / 4)), dim3(256), 0, stream, src, S_src,
                      src_off, dst_f32, (bf16_t*)dst_bf16, S_dst, dst_off, B, n, C);
+  return lc2is_check_launch();
+}
+
+extern "C" int lc2is_rows_copy_bf16(const void* src, int S_src, int src_off, float* dst_f32, void* dst_bf16,
+                                    int S_dst, int dst_off, int B, int n, int C, lc2is_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!src || (!dst_f32 && !dst_bf16)) return LC2IS_ERR_NULL;
+  if (B <= 0 || n <= 0 || C <= 0 || C % 4 || src_off < 0 || dst_off < 0 || src_off + n > S_src ||
+      dst_off + n > S_dst)
+    return LC2IS_ERR_SHAPE;
+  hipLaunchKernelGGL(rows_copy_bf16_kernel, dim3(ew_grid((size_t)B * n * C / 4)), dim3(256), 0, stream, (const bf16_t*)src,
+                     S_src, src_off, dst_f32, (bf16_t*)dst_bf16, S_dst, dst_off, B, n, C);
   return lc2is_check_launch();
 }
 

@@ -156,24 +156,40 @@ def _stack_shadows(stack: _Stack, a: ClipArch, device):
     return per, entries
 
 
+# The residual stream of the towers (round 5, LC2IS_RESID_STREAM=bf16|f32): in bf16 the two residual joins of a layer are
+# `bf16(acc + bias + x)` epilogues (fp32 add, ONE rounding; LC2IS_ACT_ADD_AUX) that read 2 and write 2 bytes per element instead of
+# 4 + 4, LayerNorm reads 2 instead of 4 (forward and backward), and the saved x / x_mid halve.  Cost: the stream is rounded to 8
+# significant bits at each of the 2 x layers joins; what that does to the logits and the gradients is measured by the full-depth
+# gates of tests/test_gpu_parity2.py.
+_RESID_BF16 = __import__('os').environ.get("LC2IS_RESID_STREAM", "bf16") != "f32"
+
+
 def _stack_fwd(x, stack: _Stack, sh, a: ClipArch, B: int, S: int, kbias, causal: bool, save: bool):
-    """x fp32 [B*S, C] residual stream -> (x_out fp32, saved list).  hf:modeling_clip.py:362-383 per layer."""
+    """x [B*S, C] residual stream (bf16 when _RESID_BF16, else fp32) -> (x_out in the same type, saved list).
+    hf:modeling_clip.py:362-383 per layer."""
     C, H = a.hidden, a.heads
     D = C // H
     scale = D ** -0.5
     saved = []
+    lean = x.dtype == torch.bfloat16
     for layer, s in zip(stack.layers, sh):
         h, _, m1, r1 = ops.layernorm_fwd(x, layer.layer_norm1.weight, layer.layer_norm1.bias, a.eps, save_stats=save)
         qkv, _, _ = ops.gemm_nt(h, s["wqkv"], s["bqkv"])
         o, lse = ops.attention_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, H, S, S, D, scale, causal=causal,
                                    kbias=kbias, save_lse=save)
-        _, x_mid, _ = ops.gemm_nt(o, s["wo"], layer.self_attn.out_proj.bias, resid=x, out_bf16=None, out_f32=True)
+        if lean:
+            x_mid, _, _ = ops.gemm_nt(o, s["wo"], layer.self_attn.out_proj.bias, resid=x)
+        else:
+            _, x_mid, _ = ops.gemm_nt(o, s["wo"], layer.self_attn.out_proj.bias, resid=x, out_bf16=None, out_f32=True)
         h2, _, m2, r2 = ops.layernorm_fwd(x_mid, layer.layer_norm2.weight, layer.layer_norm2.bias, a.eps,
                                           save_stats=save)
         # (codes 5/6 — save quick_gelu'(z), multiply in the backward — exist in the C ABI; the pair measured 4 % slower
         #  end to end than saving z: the forward variant's sigmoid temporaries spill beside the 128 accumulators)
         act, _, z = ops.gemm_nt(h2, s["w1"], layer.mlp.fc1.bias, act=ops.ACT_QUICK_GELU, aux_out=True if save else None)
-        _, x_out, _ = ops.gemm_nt(act, s["w2"], layer.mlp.fc2.bias, resid=x_mid, out_bf16=None, out_f32=True)
+        if lean:
+            x_out, _, _ = ops.gemm_nt(act, s["w2"], layer.mlp.fc2.bias, resid=x_mid)
+        else:
+            _, x_out, _ = ops.gemm_nt(act, s["w2"], layer.mlp.fc2.bias, resid=x_mid, out_bf16=None, out_f32=True)
         if save:
             saved.append((x, m1, r1, h, qkv, o, lse, x_mid, m2, r2, h2, z, act))
         x = x_out
@@ -364,15 +380,17 @@ class ImageEncoderCLIP(HipModule):
         cols = ops.patchify(pixel_values.float().contiguous(), self.patch_size, sh["kpad"])
         _, pe, _ = ops.gemm_nt(cols, sh["wpatch"], None, out_bf16=None, out_f32=True)
         x0 = ops.vit_embed_fwd(pe, emb.class_embedding, emb.position_embedding.weight, B, P)
-        _, x, m0, r0 = ops.layernorm_fwd(x0, self.enc.pre_layrnorm.weight, self.enc.pre_layrnorm.bias, a.eps,
-                                         save_stats=save, out_bf16=None, out_f32=True)
-        x, saved = _stack_fwd(x, self.enc.encoder, sh["layers"], a, B, P + 1, None, False, save)
-        if keep_cls:
+        xb, xf, m0, r0 = ops.layernorm_fwd(x0, self.enc.pre_layrnorm.weight, self.enc.pre_layrnorm.bias, a.eps,
+                                           save_stats=save, out_bf16=True if _RESID_BF16 else None,
+                                           out_f32=None if _RESID_BF16 else True)
+        x, saved = _stack_fwd(xb if _RESID_BF16 else xf, self.enc.encoder, sh["layers"], a, B, P + 1, None, False, save)
+        if keep_cls and x.dtype == torch.float32:
             out = x.view(B, P + 1, a.hidden)
-        else:
-            out = torch.empty(B * P, a.hidden, dtype=torch.float32, device=x.device)
-            ops.rows_copy(x, P + 1, 1, P, 0, B, P, dst_f32=out)
-            out = out.view(B, P, a.hidden)
+        else:   # the module's output is fp32 like the reference's: the patch rows (all rows for ...Full) leave the stream here
+            n, off = (P + 1, 0) if keep_cls else (P, 1)
+            out = torch.empty(B * n, a.hidden, dtype=torch.float32, device=x.device)
+            ops.rows_copy(x, P + 1, off, n, 0, B, n, dst_f32=out)
+            out = out.view(B, n, a.hidden)
         return out, (dict(cols=cols, x0=x0, m0=m0, r0=r0, layers=saved, B=B, P=P) if save else None)
 
     def _bwd(self, gout, saved, keep_cls):
@@ -480,6 +498,8 @@ class TextEncoderCLIP(HipModule):
         emb = self.enc.embeddings
         ids = input_ids.contiguous()
         x = ops.text_embed_fwd(ids, emb.token_embedding.weight, emb.position_embedding.weight)
+        if _RESID_BF16:
+            x = ops.cast_bf16(x)
         kbias = None
         if attention_mask is not None:
             kbias = torch.zeros(B, L, dtype=torch.float32, device=ids.device)

@@ -15,7 +15,7 @@ import torch
 from . import _lib
 
 ACT_NONE, ACT_QUICK_GELU, ACT_RELU, ACT_DQUICK_GELU, ACT_DRELU, ACT_QUICK_GELU_GRAD, ACT_MUL_AUX = 0, 1, 2, 3, 4, 5, 6
-ACT_GELU_ERF, ACT_DGELU_ERF = 7, 8
+ACT_GELU_ERF, ACT_DGELU_ERF, ACT_ADD_AUX = 7, 8, 9
 
 _P, _I, _F, _Z, _L, _U64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_long, C.c_ulonglong
 _ARGTYPES = {
@@ -51,6 +51,7 @@ _ARGTYPES = {
     "lc2is_vit_embed_bwd": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "lc2is_text_embed_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "lc2is_text_embed_bwd": [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
+    "lc2is_rows_copy_bf16": [_P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P],
     "lc2is_rows_copy_f32": [_P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P],
     "lc2is_sgd_step": [_P, _P, _P, _Z, _F, _F, _F, _F, _P],
     "lc2is_adamw_step": [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _F, _P],
@@ -152,10 +153,15 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None, 
             resid: torch.Tensor | None = None, aux_in: torch.Tensor | None = None,
             out_bf16: torch.Tensor | bool | None = True, out_f32: torch.Tensor | bool | None = None,
             aux_out: torch.Tensor | bool | None = None, tile_cfg: int = 0):
-    """out = epi(a @ w.T + bias) (+ resid).  a [M,K] bf16, w [N,K] bf16, bias fp32 [N], resid fp32 [M,N].
+    """out = epi(a @ w.T + bias) (+ resid).  a [M,K] bf16, w [N,K] bf16, bias fp32 [N], resid fp32 [M,N] — or bf16 (a bf16
+    residual stream: the add runs as the ACT_ADD_AUX epilogue, needs act == ACT_NONE and no other aux_in).
     ``out_bf16`` / ``out_f32`` / ``aux_out``: True = allocate, tensor = write into it, None/False = skip.
     Returns (out_bf16, out_f32, aux_out) with None for skipped outputs."""
     _chk(a, torch.bfloat16, "a"); _chk(w, torch.bfloat16, "w")
+    if resid is not None and resid.dtype == torch.bfloat16:
+        if act != ACT_NONE or aux_in is not None:
+            raise RuntimeError("lc2is_amd.gemm_nt: a bf16 residual needs act == ACT_NONE and no aux_in")
+        act, aux_in, resid = ACT_ADD_AUX, resid, None
     _chk(bias, torch.float32, "bias", 1); _chk(resid, torch.float32, "resid"); _chk(aux_in, torch.bfloat16, "aux_in")
     M, K = a.shape
     N, K2 = w.shape
@@ -604,7 +610,7 @@ def text_embed_fwd(ids, tok, pos):
 
 
 def text_embed_bwd(ids, dx, dtok, dpos, accumulate: bool = False):
-    """dtok must already hold the running gradient (or zeros): the scatter uses fp32 atomics."""
+    """dtok must already hold the running gradient (or zeros); per-token sums in row order, no atomics (reproducible)."""
     _chk(ids, torch.int64, "input_ids"); _chk(dx, torch.float32, "dx")
     B, L = ids.shape
     V, Cc = dtok.shape
@@ -614,15 +620,16 @@ def text_embed_bwd(ids, dx, dtok, dpos, accumulate: bool = False):
 
 def rows_copy(src, S_src: int, src_off: int, S_dst: int, dst_off: int, B: int, n: int, *, dst_f32=None,
               dst_bf16=None):
-    _chk(src, torch.float32, "src")
+    sb = src.dtype == torch.bfloat16
+    _chk(src, torch.bfloat16 if sb else torch.float32, "src")
     Cc = src.shape[1]
     if not src.is_contiguous() or src.shape[0] != B * S_src:
         raise RuntimeError("lc2is_amd.rows_copy: src must be contiguous [B*S_src, C]")
     for t in (dst_f32, dst_bf16):
         if t is not None and (not t.is_contiguous() or tuple(t.shape) != (B * S_dst, Cc)):
             raise RuntimeError("lc2is_amd.rows_copy: dst must be contiguous [B*S_dst, C]")
-    _lib.check(_fn("lc2is_rows_copy_f32")(_ptr(src), S_src, src_off, _ptr(dst_f32), _ptr(dst_bf16), S_dst,
-                                          dst_off, B, n, Cc, _stream()), "rows_copy")
+    _lib.check(_fn("lc2is_rows_copy_bf16" if sb else "lc2is_rows_copy_f32")(_ptr(src), S_src, src_off, _ptr(dst_f32), _ptr(dst_bf16),
+                                                                            S_dst, dst_off, B, n, Cc, _stream()), "rows_copy")
 
 
 def sgd_step(params, grads, momentum_buf, lr, momentum=0.0, weight_decay=0.0, grad_scale=1.0):

@@ -362,6 +362,36 @@ def test_layernorm_fwd_bwd(dev, M, C):
     assert _rel(dxf2, xd.grad) < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(2050 + 32, 768, 768), (4100, 768, 3072), (300, 512, 128), (2080, 1024, 256), (66000, 512, 64), (70, 64, 64)])
+def test_gemm_nt_bf16_residual_epilogue(dev, M, N, K):
+    """Round 5: `out = bf16(a @ w.T + bias + resid)` with a BF16 residual (the bf16 residual stream; LC2IS_ACT_ADD_AUX).  fp32 add,
+    one rounding: against fp64 of the same bf16 inputs the result is exact to bf16 rounding; every tile plan that takes the
+    problem — the default dispatch (256x384 tiles + folded ragged rows at N = 768, the persistent ping-pong form, 128x128 tiles)
+    and the forced single-kernel plans — gives bitwise the same tensor."""
+    from lc2is_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    a = _bf(torch.randn(M, K, generator=g)).to(dev)
+    w = _bf(torch.randn(N, K, generator=g) * 0.1).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    resid = _bf(torch.randn(M, N, generator=g) * 3).to(dev)
+    ref = a.double() @ w.double().T + bias.double() + resid.double()
+    out0, of, _ = ops.gemm_nt(a, w, bias, resid=resid)
+    assert of is None and out0.dtype == torch.bfloat16
+    assert _rel(out0.float(), ref) < 3e-3
+    assert (out0.double() - ref).abs().max().item() <= 2.0 ** -8 * ref.abs().max().item() + 1e-6   # one bf16 rounding of the fp32 sum
+    for cfg in (4, 6, 1, 3, 15, 16):
+        try:
+            o, _, _ = ops.gemm_nt(a, w, bias, resid=resid, tile_cfg=cfg)
+        except RuntimeError:
+            continue          # a plan that does not take this shape (16: N % 384, 15: ...)
+        assert torch.equal(o, out0), cfg
+    # the spelled-out form of the same epilogue
+    o2, _, _ = ops.gemm_nt(a, w, bias, act=ops.ACT_ADD_AUX, aux_in=resid)
+    assert torch.equal(o2, out0)
+    with pytest.raises(RuntimeError):
+        ops.gemm_nt(a, w, bias, resid=resid, act=ops.ACT_RELU)
+
+
 @pytest.mark.parametrize("M,C", [(300, 768), (77, 1024), (1025, 64)])
 def test_layernorm_bf16_streams(dev, M, C):
     """Round 5: the residual stream (x) and the gradient stream (dres) may arrive in bf16.  The kernels widen them on the way
