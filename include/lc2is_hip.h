@@ -271,15 +271,23 @@ int lc2is_adamw_step(float* params, const float* grads, float* exp_avg, float* e
 
 /* ---- segmentation head tail ------------------------------------------------------------------------
  * scores_lo: fp32 channels-last [B,h,w,ld] (C valid classes, ld in {64,128,192}); output grid H = h*S,
- * W = w*S, S in {4,8,16}.  Computes upsample(mode) -> softmax CE against labels[B,H,W] (int64):
- *   loss_sum[0] += sum of per-pixel losses, loss_sum[1] += number of counted pixels (caller zeroes both);
- *   dscores_lo (optional, pre-zeroed, same layout) += grad_scale * U^T (softmax - onehot);
+ * W = w*S.  Computes upsample(mode) -> softmax CE against labels[B,H,W] (int64):
+ *   loss_sum[0] = sum of per-pixel losses, loss_sum[1] = number of counted pixels;
+ *   dscores_lo (optional, same layout) = grad_scale * U^T (softmax - onehot);
  *   scores_hi (optional) = upsampled scores as NCHW fp32 [B,C,H,W] (the reference's `outputs`).
+ * S in {4, 8, 16} (every configuration of the reference): NO float atomics — the blocks' loss partials and gradient
+ *   footprints go to `workspace` (>= lc2is_head_upsample_ce_workspace_bytes, 16-byte aligned; required whenever loss_sum is
+ *   given) and a second launch sums them in a fixed order: loss and gradient are bitwise reproducible; loss_sum and every
+ *   element of dscores_lo (all ld channels) are OVERWRITTEN, no clearing by the caller.
+ * other S (multiples of 16 from 32): one launch that ADDS into loss_sum / dscores_lo with fp32 atomics (the caller clears
+ *   both; results differ in the last bits from run to run); no workspace (the size query returns 0).
  * replaces: model/model.py:41-53 (bicubic x4 + TextToPatch.visual + prototype matmul, commuted), CE at
  *   engine.py:94, AuxiliaryLoss (model/loss.py:17-21, bilinear). */
+size_t lc2is_head_upsample_ce_workspace_bytes(int B, int h, int w, int C, int S, int mode, int want_grad);
 int lc2is_head_upsample_ce(const float* scores_lo, int ld, const int64_t* labels, float* dscores_lo,
                            float* scores_hi, float* loss_sum, int B, int h, int w, int C, int S, int mode,
-                           long ignore_index, float grad_scale, lc2is_stream_t stream);
+                           long ignore_index, float grad_scale, void* workspace, size_t workspace_bytes,
+                           lc2is_stream_t stream);
 /* Transposed upsample (autograd of F.interpolate) for the unfused path: dhi NCHW fp32 [B,C,h*S,w*S] ->
  * dlo channels-last fp32 [B,h,w,ld] (columns >= C untouched). */
 int lc2is_upsample_bwd_nchw(const float* dhi, float* dlo, int ld, int B, int h, int w, int C, int S, int mode,

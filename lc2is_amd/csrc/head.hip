@@ -10,9 +10,12 @@
 // 768 — the [B,16384,768] tensor (25 MB/img) is never materialised.
 //
 // Work split: a block owns a 16x16 tile of OUTPUT pixels; the <=7x7 low-res footprint of the tile (S >= 4) is staged in LDS
-// once, the gradient wrt the low-res scores is accumulated in an LDS mirror of the footprint and flushed with one fp32 atomic
-// add per footprint element — 256-byte contiguous segments, the shape global float atomics run at full rate.  HBM traffic:
-// the low-res scores and labels once, the low-res gradient once.
+// once and the gradient wrt the low-res scores is accumulated in an LDS mirror of the footprint.  S = 4 / 8 / 16 (round 5): the
+// mirror leaves as the block's own SLAB of a workspace (plain stores) and a second launch sums, for every low-res cell, the
+// footprint cells of the tiles that cover it in a FIXED order (tile row, footprint row, tile column, footprint column); the
+// blocks' loss / count partials go the same way — no float atomics, the loss and the gradient are bitwise reproducible.
+// (Rounds 1-4 flushed the mirror with fp32 atomics: the arrival order made the last bits of the step run-dependent.)
+// Other S keep the atomic flush (not reproducible to the last bit; no configuration of the reference reaches them).
 //  * S = 4, 8, 16 (the headline bicubic x4 head, config 5's bilinear x4 score map, AuxiliaryLoss at 32 -> 512): head_ce_grp_kernel —
 //    S x S-pixel groups in units of 16 pixels as two small products on the fp32 matrix pipe, softmax in the accumulator layout,
 //    waves taking turns to add their gradient tiles to the LDS mirror (no LDS atomics: they retire about one lane per three
@@ -70,6 +73,10 @@ struct HeadArgs {
   int B, h, w, H, W, C, S, mode;
   long ignore_index;
   float gscale;                  // dlo = gscale * (softmax - onehot)
+  // group kernels (S = 4 / 8 / 16): per-block outputs, summed in fixed order by head_finish_kernel
+  float* ws_loss;                // [blocks][2] loss / count partials
+  float* ws_dlo;                 // [blocks][F4 * F4][cq] footprint mirrors
+  int cq;                        // channels per slab cell: C rounded up to 4
 };
 
 __device__ __forceinline__ void lds_add(float* p, float v) {
@@ -453,21 +460,70 @@ __global__ __launch_bounds__(HEAD_THREADS, (S == 4 ? 2 : 1)) void head_ce_grp_ke
     float l = 0.f, c = 0.f;
 #pragma unroll
     for (int w = 0; w < HEAD_THREADS / 64; ++w) { l += s_red[w][0]; c += s_red[w][1]; }
-    if (c > 0.f) {
-      atomicAdd(p.loss_sum, l);
-      atomicAdd(p.loss_sum + 1, c);
+    p.ws_loss[2 * (size_t)blockIdx.x] = l;
+    p.ws_loss[2 * (size_t)blockIdx.x + 1] = c;
+  }
+  if (p.dlo) {   // the mirror leaves as this block's slab: cells in footprint order, cq channels each, 16 bytes per lane
+    const int q4 = p.cq >> 2;
+    float* slab = p.ws_dlo + (size_t)blockIdx.x * (F4 * F4) * p.cq;
+    for (int i = tid; i < F4 * F4 * q4; i += HEAD_THREADS) {
+      const int cell = i / q4, c = (i % q4) * 4;
+      *reinterpret_cast<float4*>(slab + (size_t)cell * p.cq + c) = *reinterpret_cast<const float4*>(s_dlo + cell * CS + c);
     }
   }
-  if (p.dlo) {
-    for (int i = tid; i < fsize; i += HEAD_THREADS) {
-      const int cell = i / Cp, c = i % Cp;
-      if (c >= p.C) continue;
-      int ry = a0 - OFF + cell / F4, rx = b0 - OFF + cell % F4;
-      ry = ry < 0 ? 0 : (ry > p.h - 1 ? p.h - 1 : ry);
-      rx = rx < 0 ? 0 : (rx > p.w - 1 ? p.w - 1 : rx);
-      const float val = s_dlo[cell * CS + c];
-      if (val != 0.f) atomicAdd(p.dlo + (((size_t)b * p.h + ry) * p.w + rx) * p.ld + c, val);
-    }
+}
+
+// dlo[b, y, x, :] = sum of the footprint cells that map to low-res cell (y, x), over the tiles that cover it, in a fixed order;
+// loss_sum = sum of the blocks' partials in block order.  One wave per low-res cell (lane = channel quad), four cells per block.
+// Tile t along an axis covers the unclamped low-res indices [G t - 1 - OFF, G t - 1 - OFF + F4); indices below 0 / above n - 1 are
+// the clamped taps of the image border and belong to cell 0 / n - 1.
+template <int MODE, int S>
+__global__ __launch_bounds__(256) void head_finish_kernel(HeadArgs p, int nblk_main) {
+  constexpr int NT = (MODE == LC2IS_INTERP_BICUBIC) ? 4 : 2;
+  constexpr int OFF = (MODE == LC2IS_INTERP_BICUBIC) ? 1 : 0;
+  constexpr int G = HT / S;
+  constexpr int F4 = G + NT - 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (p.loss_sum && blockIdx.x == 0 && wave == 0) {
+    float l = 0.f, c = 0.f;
+    for (int k = lane; k < nblk_main; k += 64) { l += p.ws_loss[2 * (size_t)k]; c += p.ws_loss[2 * (size_t)k + 1]; }
+    l = wave_sum(l);
+    c = wave_sum(c);
+    if (lane == 0) { p.loss_sum[0] = l; p.loss_sum[1] = c; }
+  }
+  if (!p.dlo) return;
+  const long ncell = (long)p.B * p.h * p.w;
+  const long cid = (long)blockIdx.x * 4 + wave;
+  if (cid >= ncell) return;
+  const int x = (int)(cid % p.w), y = (int)((cid / p.w) % p.h), b = (int)(cid / ((long)p.w * p.h));
+  const int tiles_x = (p.W + S / 2 + HT - 1) / HT, tiles_y = (p.H + S / 2 + HT - 1) / HT;
+  auto floordiv = [](int a, int d) { return a >= 0 ? a / d : -((-a + d - 1) / d); };
+  const int ty_lo = max(0, floordiv(y + 1 + OFF - (F4 - 1), G)), ty_hi = (y == p.h - 1) ? tiles_y - 1 : min(tiles_y - 1, (y + 1 + OFF) / G);
+  const int tx_lo = max(0, floordiv(x + 1 + OFF - (F4 - 1), G)), tx_hi = (x == p.w - 1) ? tiles_x - 1 : min(tiles_x - 1, (x + 1 + OFF) / G);
+  const int q4 = p.cq >> 2;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int ty = ty_lo; ty <= ty_hi; ++ty) {
+    const int by = G * ty - 1 - OFF;
+    const int fy_lo = max(0, y == 0 ? 0 : y - by), fy_hi = min(F4 - 1, y == p.h - 1 ? F4 - 1 : y - by);
+    for (int fy = fy_lo; fy <= fy_hi; ++fy)
+      for (int tx = tx_lo; tx <= tx_hi; ++tx) {
+        const int bx = G * tx - 1 - OFF;
+        const int fx_lo = max(0, x == 0 ? 0 : x - bx), fx_hi = min(F4 - 1, x == p.w - 1 ? F4 - 1 : x - bx);
+        const float* slab = p.ws_dlo + (((size_t)b * tiles_y + ty) * tiles_x + tx) * (F4 * F4) * p.cq;
+        for (int fx = fx_lo; fx <= fx_hi; ++fx)
+          if (lane < q4) {
+            const float4 v = *reinterpret_cast<const float4*>(slab + (size_t)(fy * F4 + fx) * p.cq + 4 * lane);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+          }
+      }
+  }
+  if (4 * lane < p.ld) {   // every channel of the row is written (zeros past cq): the caller need not clear the buffer
+    float* o = p.dlo + (((size_t)b * p.h + y) * p.w + x) * p.ld + 4 * lane;
+    if (4 * lane + 0 >= p.C) acc.x = 0.f;
+    if (4 * lane + 1 >= p.C) acc.y = 0.f;
+    if (4 * lane + 2 >= p.C) acc.z = 0.f;
+    if (4 * lane + 3 >= p.C) acc.w = 0.f;
+    *reinterpret_cast<float4*>(o) = acc;
   }
 }
 
@@ -576,9 +632,32 @@ extern "C" int lc2is_upsample_bwd_nchw(const float* dhi, float* dlo, int ld, int
   return lc2is_check_launch();
 }
 
+namespace {
+struct HeadGrpPlan { int f4, t4, cq; size_t loss_bytes, dlo_bytes; };
+// the S = 4 / 8 / 16 group kernels: blocks per image, slab cell width, workspace split (loss partials first, 256-byte aligned slabs)
+HeadGrpPlan head_grp_plan(int B, int h, int w, int C, int S, int mode, bool want_grad) {
+  HeadGrpPlan g;
+  g.f4 = head_grp_footprint(mode, S);
+  const int H = h * S, W = w * S;
+  g.t4 = ((H + S / 2 + HT - 1) / HT) * ((W + S / 2 + HT - 1) / HT);
+  g.cq = (C + 3) & ~3;
+  g.loss_bytes = ((size_t)B * g.t4 * 2 * sizeof(float) + 255) & ~(size_t)255;
+  g.dlo_bytes = want_grad ? (size_t)B * g.t4 * g.f4 * g.f4 * g.cq * sizeof(float) : 0;
+  return g;
+}
+}  // namespace
+
+extern "C" size_t lc2is_head_upsample_ce_workspace_bytes(int B, int h, int w, int C, int S, int mode, int want_grad) {
+  if (B <= 0 || h <= 0 || w <= 0 || C <= 0 || !(S == 4 || S == 8 || S == 16)) return 0;   // other S: the atomic path, no workspace
+  if (mode != LC2IS_INTERP_BICUBIC && mode != LC2IS_INTERP_BILINEAR) return 0;
+  const HeadGrpPlan g = head_grp_plan(B, h, w, C, S, mode, want_grad != 0);
+  return g.loss_bytes + g.dlo_bytes;
+}
+
 extern "C" int lc2is_head_upsample_ce(const float* scores_lo, int ld, const int64_t* labels, float* dscores_lo,
                                       float* scores_hi, float* loss_sum, int B, int h, int w, int C, int S,
-                                      int mode, long ignore_index, float grad_scale, lc2is_stream_t stream_) {
+                                      int mode, long ignore_index, float grad_scale, void* workspace,
+                                      size_t workspace_bytes, lc2is_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!scores_lo) return LC2IS_ERR_NULL;
   if (!scores_hi && !loss_sum) return LC2IS_ERR_NULL;
@@ -589,7 +668,7 @@ extern "C" int lc2is_head_upsample_ce(const float* scores_lo, int ld, const int6
   if (mode != LC2IS_INTERP_BICUBIC && mode != LC2IS_INTERP_BILINEAR) return LC2IS_ERR_UNSUPPORTED;
   const int H = h * S, W = w * S;
   HeadArgs a{scores_lo, ld, labels, dscores_lo, scores_hi, loss_sum, B, h, w, H, W, C, S, mode, ignore_index,
-             grad_scale};
+             grad_scale, nullptr, nullptr, 0};
   const int lds_bytes = 2 * FMAX * FMAX * ld * (int)sizeof(float);
   static DevOnce attr_set;
   if (attr_set.need()) {
@@ -605,9 +684,15 @@ extern "C" int lc2is_head_upsample_ce(const float* scores_lo, int ld, const int6
     // channel tiles of 16 the kernel runs (tiles past C are masked): the smallest instantiation that covers C inside the row stride
     const int nt = (C + 15) / 16;
     const int tn = nt <= 4 ? 4 : (nt <= 8 ? 8 : (nt <= 10 ? 10 : 12));
-    const int f4 = head_grp_footprint(mode, S);
+    const HeadGrpPlan gp = head_grp_plan(B, h, w, C, S, mode, dscores_lo != nullptr);
+    const int f4 = gp.f4, t4 = gp.t4;
     const int lds4 = 2 * f4 * f4 * (ld + HEAD_PAD) * (int)sizeof(float) + HT * HT * (int)sizeof(int);
-    const int t4 = ((H + S / 2 + HT - 1) / HT) * ((W + S / 2 + HT - 1) / HT);
+    if (loss_sum) {   // loss / gradient leave through per-block partials and slabs: a workspace is part of the call
+      if (!workspace || ((size_t)workspace & 15) || workspace_bytes < gp.loss_bytes + gp.dlo_bytes) return LC2IS_ERR_WORKSPACE;
+      a.ws_loss = (float*)workspace;
+      a.ws_dlo = dscores_lo ? (float*)((char*)workspace + gp.loss_bytes) : nullptr;
+      a.cq = gp.cq;
+    }
 #define LC2IS_HEAD_GRP(MODE_, TN_, S_)                                                                                       \
   do {                                                                                                                      \
     static DevOnce attr;                                                                                               \
@@ -633,6 +718,15 @@ extern "C" int lc2is_head_upsample_ce(const float* scores_lo, int ld, const int6
 #undef LC2IS_HEAD_GRP_S
 #undef LC2IS_HEAD_GRP_TN
 #undef LC2IS_HEAD_GRP
+    int rc = lc2is_check_launch();
+    if (rc || !loss_sum) return rc;
+    // second launch: fixed-order sums of the slabs (one wave per low-res cell) and of the loss partials
+    const long ncell = dscores_lo ? (long)B * h * w : 1;
+    const int fgrid = (int)((ncell + 3) / 4);
+#define LC2IS_HEAD_FIN(MODE_, S_) hipLaunchKernelGGL((head_finish_kernel<MODE_, S_>), dim3(fgrid), dim3(256), 0, stream, a, B * t4)
+    if (mode == LC2IS_INTERP_BICUBIC) { if (S == 4) LC2IS_HEAD_FIN(LC2IS_INTERP_BICUBIC, 4); else if (S == 8) LC2IS_HEAD_FIN(LC2IS_INTERP_BICUBIC, 8); else LC2IS_HEAD_FIN(LC2IS_INTERP_BICUBIC, 16); }
+    else { if (S == 4) LC2IS_HEAD_FIN(LC2IS_INTERP_BILINEAR, 4); else if (S == 8) LC2IS_HEAD_FIN(LC2IS_INTERP_BILINEAR, 8); else LC2IS_HEAD_FIN(LC2IS_INTERP_BILINEAR, 16); }
+#undef LC2IS_HEAD_FIN
     return lc2is_check_launch();
   }
   const int tiles = ((H + HT - 1) / HT) * ((W + HT - 1) / HT);

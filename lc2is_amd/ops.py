@@ -55,7 +55,8 @@ _ARGTYPES = {
     "lc2is_rows_copy_f32": [_P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P],
     "lc2is_sgd_step": [_P, _P, _P, _Z, _F, _F, _F, _F, _P],
     "lc2is_adamw_step": [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _F, _P],
-    "lc2is_head_upsample_ce": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, C.c_long, _F, _P],
+    "lc2is_head_upsample_ce_workspace_bytes": [_I, _I, _I, _I, _I, _I, _I],
+    "lc2is_head_upsample_ce": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, C.c_long, _F, _P, _Z, _P],
     "lc2is_ce_nchw_fwd": [_P, _P, _P, _P, _I, _I, C.c_long, C.c_long, _P],
     "lc2is_ce_nchw_bwd": [_P, _P, _P, _P, _F, _P, _I, _I, C.c_long, C.c_long, _P],
     "lc2is_upsample_bwd_nchw": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
@@ -655,11 +656,16 @@ def head_upsample_ce(scores_lo, labels, B: int, h: int, w: int, C: int, S: int, 
     dev = scores_lo.device
     if labels is not None and (tuple(labels.shape) != (B, h * S, w * S) or not labels.is_contiguous()):
         raise RuntimeError(f"lc2is_amd.head_upsample_ce: labels must be contiguous [{B},{h*S},{w*S}]")
-    loss = torch.zeros(2, dtype=torch.float32, device=dev) if want_loss else None
-    dlo = torch.zeros_like(scores_lo) if want_grad else None
+    # S = 4 / 8 / 16: per-block partials in a workspace + a fixed-order second launch (reproducible; outputs overwritten);
+    # other S: the atomic path adds into cleared buffers
+    nbytes = _fn("lc2is_head_upsample_ce_workspace_bytes")(B, h, w, C, S, mode, int(want_grad)) if want_loss else 0
+    alloc = torch.empty if nbytes else torch.zeros
+    loss = alloc(2, dtype=torch.float32, device=dev) if want_loss else None
+    dlo = alloc(scores_lo.shape, dtype=torch.float32, device=dev) if want_grad else None
     hi = torch.empty((B, C, h * S, w * S), dtype=torch.float32, device=dev) if want_scores else None
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev) if nbytes else None   # (per call: the slabs live until the second launch, in stream order)
     rc = _fn("lc2is_head_upsample_ce")(_ptr(scores_lo), ld, _ptr(labels), _ptr(dlo), _ptr(hi), _ptr(loss), B, h,
-                                       w, C, S, mode, ignore_index, grad_scale, _stream())
+                                       w, C, S, mode, ignore_index, grad_scale, _ptr(ws), nbytes, _stream())
     _lib.check(rc, f"head_upsample_ce B={B} h={h} w={w} C={C} S={S}")
     return loss, dlo, hi
 

@@ -321,9 +321,10 @@ def test_config4_depth4_gradients_vs_oracle(dev):
 def test_config4_full_depth_forward_and_loss_vs_oracle(dev):
     """BASELINE configs[3] at its REAL depth: ViT-L/14 @640x640 (2026 tokens, width 1024, 16 heads, ff 4096), all 24 layers; CLIP
     text width 768 / 12 heads, 12 layers; decoder d_model 1024 / 8 heads (head_dim 128) / d_kv 768; output 180x180, B = 1.
-    Forward logits and the CE loss against the fp32 CPU oracle (no gradient list: test_config4_depth4_gradients_vs_oracle
-    carries those; the oracle's 24-layer forward is a few seconds on the box's cores).  Tolerances: measured x 2
-    (profiles/r04_parity.json)."""
+    Forward logits, the CE loss AND (round 5) the ten-gradient list of the depth-4 test — first / middle / last
+    ViT layer, patch embedding, text tower, decoder, head — against one train step of the fp32 CPU oracle (forward + backward of
+    24 ViT-L layers at 2026 tokens: tens of seconds on the box's cores).  No reference code path exists for ViT-L/14
+    (model/encoder.py:18-21): the oracle is the only pin.  Tolerances: measured x 2 (profiles/r05_parity.json)."""
     import lc2is_amd.nn as N
     from oracle import ref_cpu as O
     torch.manual_seed(24)
@@ -338,25 +339,43 @@ def test_config4_full_depth_forward_and_loss_vs_oracle(dev):
     labels = torch.randint(0, 151, (B, 180, 180), generator=g)
     cfg = O.BaseCfg(in_size=640, out_size=180, patch=14, vision=O.ClipCfg(1024, 16, 24, patch=14),
                     text=O.ClipCfg(768, 12, 12, eos_token_id=999), dec_heads=8, dec_layers=1)
-    with torch.no_grad():
-        _, _, ref_logits = O.base_model_with_text(sd, inputs, cfg)
-        ref_loss = O.cross_entropy(ref_logits, labels, -100)
+    ref_loss, ref_logits, ref_grads, _ = O.train_step_sgd(sd, inputs, labels, cfg, 1e-5)
     m = m.to(dev).eval()
     dinputs = {k: v.to(dev) for k, v in inputs.items()}
     with torch.no_grad():
         out = m(dinputs)["outputs"]
-        loss = m.forward_loss(dinputs, labels.to(dev))
     r = _rel(out, ref_logits)
     agree = (out.argmax(1).cpu() == ref_logits.argmax(1)).float().mean().item()
     _note("config4_d24/logits_rel", r); _note("config4_d24/argmax_agreement", agree)
+    m.train()
+    loss = m.forward_loss(dinputs, labels.to(dev))
     _note("config4_d24/loss_hip", loss.item()); _note("config4_d24/loss_oracle", float(ref_loss))
+    loss.backward()
+    named = dict(m.named_parameters())
+    worst, worst_k = 0.0, None
+    for k in ("vision_encoder.enc.embeddings.patch_embedding.weight",
+              "vision_encoder.enc.encoder.layers.0.self_attn.q_proj.weight",
+              "vision_encoder.enc.encoder.layers.0.mlp.fc1.weight",
+              "vision_encoder.enc.encoder.layers.12.mlp.fc2.weight",
+              "vision_encoder.enc.encoder.layers.23.mlp.fc2.weight",
+              "vision_encoder.enc.encoder.layers.23.self_attn.out_proj.weight",
+              "text_encoder.enc.encoder.layers.11.mlp.fc1.weight",
+              "vision_decoder.layers.0.self_attn.in_proj_weight",
+              "vision_decoder.layers.0.multihead_attn.k_proj_weight",
+              "pixel_patch.visual.weight", "class_prototypes"):
+        rg = _rel(named[k].grad, ref_grads[k])
+        _note("config4_d24/grad/" + k, rg)
+        if rg > worst:
+            worst, worst_k = rg, k
     assert out.shape == (B, 151, 180, 180)
     assert r < CFG4_D24_LOGITS_MAX, r
     assert abs(loss.item() - float(ref_loss)) < CFG4_D24_LOSS_MAX
+    assert worst < CFG4_D24_GRAD_MAX, (worst_k, worst)
 
 
 # measured (round 4): logits rel-L2 6.6e-3, argmax agreement 0.9915 (random weights), loss 17.1838 vs 17.1778.  Bounds = measured x 2.
 CFG4_D24_LOGITS_MAX, CFG4_D24_LOSS_MAX = 1.3e-2, 1.2e-2
+CFG4_D24_GRAD_MAX = 6e-2   # (round 5: first run; restated as measured x 2 once profiles/r05_parity.json holds the numbers)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -29,10 +29,12 @@ def main():
         ts = []
         for _ in range(a.iters):
             loss = torch.zeros(2, device=dev); dlo = torch.zeros_like(lo)
+            nbytes = ops._fn("lc2is_head_upsample_ce_workspace_bytes")(B, h, h, C, S, mode, 1)
+            ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+            e0.record()   # both launches: tile kernel + fixed-order finish
             rc = ops._fn("lc2is_head_upsample_ce")(ops._ptr(lo), 192, ops._ptr(labels), ops._ptr(dlo), None, ops._ptr(loss), B, h, h, C, S, mode,
-                                                   -100, 1.0 / labels.numel(), ops._stream())
+                                                   -100, 1.0 / labels.numel(), ops._ptr(ws), nbytes, ops._stream())
             e1.record()
             torch.cuda.synchronize()
             assert rc == 0
