@@ -57,7 +57,9 @@ const char* lc2is_version(void);
 /* Compute units the GEMM tile planners may count on (0 = all 256, the default).  The large-tile kernels run one block per CU and
  * their plans are whole rounds of the CUs; a CU held by another queue's kernel for the duration (RCCL's channels while gradients
  * are reduced under the backward pass) would turn "exactly one round" into two.  With a budget n the persistent kernels launch n
- * blocks and every round count is taken over n CUs.  Process-wide; results do not depend on it (every plan is bitwise equal).
+ * blocks and every round count is taken over n CUs.  Process-wide.  The NT GEMM plans are bitwise equal under any budget; the
+ * weight-gradient plans (lc2is_gemm_tn_bf16 / _grouped) choose their M-split count from it, i.e. the ORDER of their fp32 partial
+ * sums: their results move in the last bits with the budget (each call reads the budget once and is reproducible for a given value).
  * replaces: nothing in the reference (torch DDP leaves this to the vendor GEMM library's heuristics). */
 int lc2is_set_cu_budget(int ncu);
 int lc2is_get_cu_budget(void);
@@ -120,8 +122,10 @@ int lc2is_gemm_tn_grouped(const lc2is_tn_problem* problems, int n, void* workspa
    every such image (returns how many): call it once ALL graphs captured so far have been destroyed.  Per-graph ownership:
    lc2is_captured_tables_mark() before and after a capture brackets the images that capture registered, and
    lc2is_release_captured_tables_range(first, last) frees exactly those once that graph is destroyed (lc2is_amd.step.TrainStep
-   does, when a captured step is released or captured again) — other live graphs keep theirs.  No reference counterpart
-   (host-side resource management). */
+   does, when a captured step is released or captured again) — other live graphs keep theirs.  Slots are never reused or
+   removed (a released slot stays empty), so marks stay valid across either release call; the global release is for
+   tear-down only — it also frees images of graphs that are still alive.  No reference counterpart (host-side resource
+   management). */
 int lc2is_release_captured_tables(void);
 int lc2is_captured_tables_mark(void);
 int lc2is_release_captured_tables_range(int first, int last);

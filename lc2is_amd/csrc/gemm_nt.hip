@@ -1162,14 +1162,12 @@ int launch_by_cfg(const GemmNtArgs& a_in, int cfg, hipStream_t stream) {
   GemmNtArgs a = a_in;
   const bool f32_staged = a.staged_epi == 2;
   if (f32_staged) a.staged_epi = 0;
-  static const bool per_act = !(getenv("LC2IS_GEMM_PER_ACT") && atoi(getenv("LC2IS_GEMM_PER_ACT")) == 0);
   switch (cfg) {
     case 1: return launch_cfg<128, 128, 2, 2>(a, stream);
     case 2: return launch_cfg<256, 128, 4, 2>(a, stream);
     case 3: return launch_cfg<64, 64, 2, 2>(a, stream);
     case 4:
       if (f32_staged) return launch_dma<256, 256, 2, 4, -2>(a, stream);
-      if (!per_act) return launch_dma<256, 256, 2, 4>(a, stream);
       switch (a.act) {
         case LC2IS_ACT_QUICK_GELU: return launch_dma<256, 256, 2, 4, LC2IS_ACT_QUICK_GELU>(a, stream);
         case LC2IS_ACT_RELU: return launch_dma<256, 256, 2, 4, LC2IS_ACT_RELU>(a, stream);
@@ -1179,11 +1177,11 @@ int launch_by_cfg(const GemmNtArgs& a_in, int cfg, hipStream_t stream) {
         case LC2IS_ACT_DGELU_ERF: return launch_dma<256, 256, 2, 4, LC2IS_ACT_DGELU_ERF>(a, stream);
         case LC2IS_ACT_NONE: return launch_dma<256, 256, 2, 4, LC2IS_ACT_NONE>(a, stream);
         case LC2IS_ACT_ADD_AUX: return launch_dma<256, 256, 2, 4, LC2IS_ACT_ADD_AUX>(a, stream);
-        default: return launch_dma<256, 256, 2, 4>(a, stream);   // codes 5 / 6 (experiments) keep the run-time switch
+        default: return launch_dma<128, 128, 2, 2>(a, stream);   // codes 5 / 6 (the save-the-derivative experiment): the 128x128 kernel's run-time switch
+                                                                 // (the 256x256 instantiation of it spilled 128 bytes and left the library in round 5)
       }
     case 6:
       if (f32_staged) return launch_dma<128, 128, 2, 2, -2>(a, stream);
-      if (!per_act) return launch_dma<128, 128, 2, 2>(a, stream);
       switch (a.act) {   // the activations of the Swin / hierarchical-decoder GEMMs that land on this tile size
         case LC2IS_ACT_RELU: return launch_dma<128, 128, 2, 2, LC2IS_ACT_RELU>(a, stream);
         case LC2IS_ACT_DRELU: return launch_dma<128, 128, 2, 2, LC2IS_ACT_DRELU>(a, stream);

@@ -37,12 +37,13 @@ inline int tn_forced_cfg() {  // LC2IS_GEMM_TN_CFG=1|2 pins the kernel choice (t
   return cfg;
 }
 
-inline TnPlan tn_plan(int M, int N, int K) {
+// `ncu`: the CU budget, read ONCE per call by the entry point (a planner that re-read the process-wide atomic could see two values)
+inline TnPlan tn_plan(int M, int N, int K, int ncu) {
   TnPlan p;
   p.big = 0;
   if (N % 256 == 0 && K % 256 == 0 && tn_forced_cfg() != 1) {
     const int ntn = N / 256, ntk = K / 256, tiles = ntn * ntk;
-    int splits = (lc2is_ncu() + tiles / 2) / tiles;   // about one block per CU of the budget (common.h)
+    int splits = (ncu + tiles / 2) / tiles;   // about one block per CU of the budget (common.h)
     const int max_splits = (M + 511) / 512;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -595,10 +596,14 @@ inline int colsum_parts(int M) {
 
 }  // namespace
 
+static size_t tn_plan_bytes(const TnPlan& p, int N, int K) {
+  return p.splits > 1 ? (size_t)p.splits * N * ((size_t)K + 1) * sizeof(float) : 0;
+}
+
 extern "C" size_t lc2is_gemm_tn_workspace_bytes(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  const TnPlan p = tn_plan(M, N, K);
-  return p.splits > 1 ? (size_t)p.splits * N * ((size_t)K + 1) * sizeof(float) : 0;
+  const TnPlan p = tn_plan(M, N, K, lc2is_ncu());
+  return tn_plan_bytes(p, N, K);
 }
 
 extern "C" int lc2is_gemm_tn_bf16(const void* dY, int ldy, const void* X, int ldx, float* dW, int ldw, float* db,
@@ -610,8 +615,8 @@ extern "C" int lc2is_gemm_tn_bf16(const void* dY, int ldy, const void* X, int ld
   if (ldy < N || ldx < K || ldw < K || ldy % 8 || ldx % 8 || ldw % 4) return LC2IS_ERR_SHAPE;
   if ((double)(M + 64) * ldy * 2.0 >= 2147483648.0 || (double)(M + 64) * ldx * 2.0 >= 2147483648.0)
     return LC2IS_ERR_UNSUPPORTED;
-  const TnPlan p = tn_plan(M, N, K);
-  const size_t need = lc2is_gemm_tn_workspace_bytes(M, N, K);
+  const TnPlan p = tn_plan(M, N, K, lc2is_ncu());   // ONE read of the CU budget: the launch and its workspace need come from this plan
+  const size_t need = tn_plan_bytes(p, N, K);
   if (need && (!workspace || workspace_bytes < need)) return LC2IS_ERR_WORKSPACE;
   static DevOnce attr_set;
   if (attr_set.need()) {
@@ -682,7 +687,7 @@ inline int tg_valid(const lc2is_tn_problem* pr, int n) {
 //  (tail)    every tile a full-length block except a few small problems that are split so finely that their blocks fill
 //            the last, partly empty round (a whole tower, 1296 tiles: 1278 full blocks in 5 rounds + 18 tiles x 14 splits)
 //            — no slabs for the bulk and ~97 % of the CUs busy instead of 84 %.
-inline void tg_plan(const lc2is_tn_problem* pr, int n, TgPlan& pl) {
+inline void tg_plan(const lc2is_tn_problem* pr, int n, TgPlan& pl, const int ncu) {
   pl.small = false;
   for (int i = 0; i < n; ++i)
     if (pr[i].N % 256 || pr[i].K % 256) pl.small = true;
@@ -725,12 +730,12 @@ inline void tg_plan(const lc2is_tn_problem* pr, int n, TgPlan& pl) {
   double best_t = 1e300;
   for (int sp = 1; sp <= max_splits; ++sp) {
     const long blocks = tiles * sp;
-    const double rounds = (double)lc2is_rounds(blocks);
+    const double rounds = (double)((blocks + ncu - 1) / ncu);
     const double t = rounds * ((max_steps + sp - 1) / sp + 13.0) + (sp > 1 ? sp * wbytes * slab_unit : 0.0);
     if (t < best_t) { best_t = t; best = sp; }
   }
   for (int i = 0; i < n; ++i) { pl.splits[i] = best; pl.order[i] = i; }
-  const int ncu = lc2is_ncu();   // (256, or the budget set while another queue's kernels hold CUs: common.h)
+  // (ncu: 256, or the budget set while another queue's kernels hold CUs: common.h)
   const int rem = (int)(tiles % ncu);
   if (n > 1 && tiles > ncu && rem != 0 && max_splits >= 2) {
     bool in_tail[TG_TBL_MAX] = {};
@@ -748,7 +753,7 @@ inline void tg_plan(const lc2is_tn_problem* pr, int n, TgPlan& pl) {
     int sp = ts > 0 ? ncu / ts : 0;
     if (sp > max_splits) sp = max_splits;
     if (ts >= rem && sp >= 2) {
-      const double rounds = (double)lc2is_rounds(tiles - ts);
+      const double rounds = (double)((tiles - ts + ncu - 1) / ncu);
       const double t = rounds * (max_steps + 13.0) + ((max_steps + sp - 1) / sp + 13.0) + sp * tail_bytes * slab_unit;
       if (t < best_t) {
         int k = 0;
@@ -769,9 +774,8 @@ static std::vector<void*> g_captured_tables;   // pinned descriptor-table images
 extern "C" int lc2is_release_captured_tables(void) {
   std::lock_guard<std::mutex> lock(g_captured_mu);
   int n = 0;
-  for (void* p : g_captured_tables)
-    if (p) { (void)hipHostFree(p); ++n; }
-  g_captured_tables.clear();
+  for (void*& p : g_captured_tables)   // the table never shrinks: marks held by other captured steps stay valid indices (their slots
+    if (p) { (void)hipHostFree(p); p = nullptr; ++n; }   // are simply empty afterwards; a later capture appends, it never reuses a slot)
   return n;
 }
 
@@ -794,7 +798,7 @@ extern "C" int lc2is_release_captured_tables_range(int first, int last) {
 extern "C" size_t lc2is_gemm_tn_grouped_workspace_bytes(const lc2is_tn_problem* problems, int n) {
   if (tg_valid(problems, n) != LC2IS_OK) return 0;
   TgPlan pl;
-  tg_plan(problems, n, pl);
+  tg_plan(problems, n, pl, lc2is_ncu());
   return pl.ws_floats * sizeof(float) + (n > TG_MAX ? TG_TBL_BYTES : 0);
 }
 
@@ -804,7 +808,7 @@ extern "C" int lc2is_gemm_tn_grouped(const lc2is_tn_problem* problems, int n, vo
   int rc = tg_valid(problems, n);
   if (rc) return rc;
   TgPlan pl;
-  tg_plan(problems, n, pl);
+  tg_plan(problems, n, pl, lc2is_ncu());
   const bool tbl = n > TG_MAX;
   const size_t need = pl.ws_floats * sizeof(float) + (tbl ? TG_TBL_BYTES : 0);
   if (need && (!workspace || workspace_bytes < need)) return LC2IS_ERR_WORKSPACE;

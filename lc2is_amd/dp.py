@@ -37,7 +37,8 @@ class GradReducer:
         self._early = {}
         # CUs left to RCCL's channel kernels while collectives are in flight (LC2IS_DP_CU_RESERVE, default 0 = plan on all 256): every
         # large-tile GEMM block takes a whole CU, so a CU held by a collective turns "one round of tiles" into two.  Set from the
-        # first all_reduce of a step to finish_step (lc2is_set_cu_budget; the plans are bitwise equal, only their shape changes).
+        # first all_reduce of a step to finish_step (lc2is_set_cu_budget; NT GEMM plans are bitwise equal under any budget, the
+        # weight-gradient plans split M differently, i.e. sum their fp32 partials in another order: last-bit differences).
         import os
         self.cu_reserve = max(0, min(128, int(os.environ.get("LC2IS_DP_CU_RESERVE", "0"))))
         self._budget_on = False

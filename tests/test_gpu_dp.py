@@ -43,10 +43,14 @@ def _worker(rank, world, port, q, backend="gloo"):
     calls = []                                   # the (lo, hi) sequence of collectives this rank issues, in issue order
     orig_all_reduce = dist.all_reduce
 
+    from lc2is_amd import ops as _ops
+    budgets = []                                 # the planners' CU budget at the moment of every collective
+
     def recording_all_reduce(t, *a, **kw):
         if t.data_ptr() >= red._flat.data_ptr() and t.numel() and t.dtype == red._flat.dtype:
             lo = (t.data_ptr() - red._flat.data_ptr()) // 4
             calls.append((int(lo), int(lo + t.numel())))
+            budgets.append(_ops.get_cu_budget())
         return orig_all_reduce(t, *a, **kw)
 
     dist.all_reduce = recording_all_reduce
@@ -66,8 +70,22 @@ def _worker(rank, world, port, q, backend="gloo"):
         inputs2["attention_mask"] = torch.ones_like(inputs["attention_mask"])
     ts.step(inputs2, labels)
     torch.cuda.synchronize()
+    # an exception inside finish_step (a failed collective) must not leave the planners on the reduced budget
+    budget_after_steps = _ops.get_cu_budget()
+
+    class _Boom:
+        def wait(self):
+            raise RuntimeError("boom")
+    red._set_budget(True)
+    red._pending.append(_Boom())
+    try:
+        red.finish_step()
+        raised = False
+    except RuntimeError:
+        raised = True
     torch.save(dict(rank=rank, loss=float(loss.item()), flat=flat1, grad=grad1, flat2=ts.arena.flat.cpu(),
-                    calls1=torch.tensor(first), calls2=torch.tensor(calls)),
+                    calls1=torch.tensor(first), calls2=torch.tensor(calls), budgets=torch.tensor(budgets),
+                    budget_after_steps=budget_after_steps, budget_after_exception=_ops.get_cu_budget(), raised=raised),
                os.path.join(q, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -121,6 +139,23 @@ def test_two_rank_step_matches_global_batch(dev, tmp_path, backend):
     assert rel < 2e-2, rel   # different batch split -> different bf16 rounding, same gradient
     relp = ((p0 - ts.arena.flat.cpu()).norm() / (0.05 * gref.norm())).item()
     assert relp < 2e-2, relp
+
+
+def test_two_rank_step_with_cu_reserve(dev, tmp_path, monkeypatch):
+    """LC2IS_DP_CU_RESERVE — the reducer lowers the planners' CU budget from the first all_reduce of a step to
+    finish_step.  Both ranks must still issue the same collectives and end with identical parameters (the budget changes the
+    weight-gradient split counts on BOTH ranks at the same program point), the budget is back to 0 after every step, and an
+    exception inside finish_step does not leave it lowered."""
+    monkeypatch.setenv("LC2IS_DP_CU_RESERVE", "16")
+    _run_two_ranks(tmp_path, "gloo")
+    r0 = torch.load(tmp_path / "rank0.pt", weights_only=True)
+    r1 = torch.load(tmp_path / "rank1.pt", weights_only=True)
+    assert torch.equal(r0["flat"], r1["flat"]) and torch.equal(r0["flat2"], r1["flat2"])
+    assert torch.equal(r0["calls1"], r1["calls1"]) and torch.equal(r0["calls2"], r1["calls2"])
+    for r in (r0, r1):
+        assert r["budgets"].numel() > 0 and set(r["budgets"].tolist()) <= {0, 240}
+        assert 240 in r["budgets"].tolist()            # in force while collectives are in flight (from the 2nd collective of a step on)
+        assert r["budget_after_steps"] == 0 and r["raised"] and r["budget_after_exception"] == 0
 
 
 def test_bench_two_ranks_gloo_end_to_end(dev, tmp_path):

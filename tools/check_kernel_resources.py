@@ -10,13 +10,14 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 CSRC = ROOT / "lc2is_amd" / "csrc"
-HOT = ("gemm_nt_pp_kernel", "gemm_nt_persist2_kernel", "gemm_nt_dma_kernel", "gemm_tn_grouped", "attn_fwd_kernel<64", "attn_fwd_kernel<96",
-       "attn_bwd_dq2_kernel<64", "attn_bwd_dkdv_kernel<64", "attn_bwd_dq2_kernel<96", "attn_bwd_dkdv_kernel<96", "attn_bwd_fused_kernel",
-       "head_ce_grp_kernel", "ln_fwd_kernel", "ln_bwd_kernel", "sgd_kernel")
-# known, accepted (listed so that a NEW spill is a failure): the run-time-switch epilogue instantiation (EPI = -1, activations 5 / 6
-# only — every headline GEMM runs a per-activation instantiation), 12 bytes in the 128-register LayerNorm backward (HBM-bound: 5.4
-# TB/s) and the opt-in fused attention backward
-ACCEPTED = ("gemm_nt_dma_kernel<256, 256, 2, 4, -1>", "gemm_nt_dma_kernel<128, 128, 2, 2, -1>", "ln_bwd_kernel<3>", "attn_bwd_fused_kernel")
+HOT = ("gemm_nt_pp_kernel", "gemm_nt_w384_kernel", "gemm_nt_rows_kernel", "gemm_nt_dma_kernel", "gemm_tn_grouped", "attn_fwd_kernel<64", "attn_fwd_kernel<96",
+       "attn_bwd_dq2_kernel<64", "attn_bwd_dkdv_kernel<64", "attn_bwd_dq2_kernel<96", "attn_bwd_dkdv_kernel<96",
+       "head_ce_grp_kernel", "head_finish_kernel", "ln_fwd_kernel", "ln_bwd_kernel", "sgd_kernel")
+# known, accepted (listed so that a NEW spill is a failure): 12 bytes (one 64-bit address + one dword, stored once in front of the row
+# loop) in the 128-register LayerNorm backward at C = 768 — HBM-bound at 5.4 TB/s; compiling it for 3 waves per SIMD instead removes the
+# spill and measured slower (round 2), and one base pointer per stream instead of fp32 / bf16 pairs made hipcc demote the row arrays to
+# the stack (48-144 bytes in every instantiation; tried in round 5).  Every OTHER kernel of the library must report zero scratch.
+ACCEPTED = ("ln_bwd_kernel<3>",)
 
 
 def demangle(names):
@@ -58,13 +59,13 @@ def main():
         flag = ""
         if r.get("scratch", 0) > 0:
             flag = "  <-- SPILLS" + (" (hot path)" if hot else "")
-            if hot and not any(a in n for a in ACCEPTED):
+            if not any(a in n for a in ACCEPTED):   # (round 5: ANY kernel of the library, not only the hot ones)
                 bad.append(n)
         print(f"{n[:90]:90s} {r['file']:24s} {r.get('vgpr', 0):5d} {r.get('agpr', 0):5d} {r.get('occ', 0):3d} {r.get('scratch', 0):7d}{flag}")
     if bad:
-        print("\nhot-path kernels with scratch:", *bad, sep="\n  ")
+        print("\nkernels with scratch:", *bad, sep="\n  ")
         sys.exit(1)
-    print("\nno hot-path kernel uses scratch")
+    print("\nno kernel of the library uses scratch")
 
 
 if __name__ == "__main__":
