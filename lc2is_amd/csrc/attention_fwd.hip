@@ -59,6 +59,9 @@ struct AttnFwdArgs {
 // torch:nn/functional.py:6206): l sums the UNDROPPED probabilities, O accumulates keep * P / (1 - p);
 // coordinate of a score = (row (b*H + h)*Sq + q, column key), so the backward kernels regenerate the same decisions.
 constexpr float FRAME_THR = 6.0f;
+#ifndef LC2IS_ATTN_LIGHT
+#define LC2IS_ATTN_LIGHT 1   // (build with -DLC2IS_ATTN_LIGHT=0 for the A/B library without the light half step)
+#endif
 
 // NQ = 32-query groups per wave.  NQ = 1: 3 waves/SIMD at D = 64.  NQ = 2 (64 queries per wave, 256 per block): every K row
 // fragment and every V^T fragment read from LDS feeds TWO MFMA chains (half the LDS bytes per MFMA, and the S^T chains of the two
@@ -224,14 +227,19 @@ __global__ __launch_bounds__(256, NQ == 2 ? (D == 64 ? 2 : 1) : ((D == 64) ? 3 :
     for (int g = 0; g < NQ; ++g) frame1(st[g], g, kt, t, masked_c);
   };
   // block 2 of a half step: P = exp2(s - m_ref), row sums, pack, O^T += V^T · P^T   (+ the next half's S^T chain, see the loop)
-  auto finish = [&](f32x16_t (&st)[NQ], int so, int kt, int t) __attribute__((always_inline)) {
+  auto exp_sum = [&](f32x16_t (&st)[NQ], f32x2_t (&hs)[NQ]) __attribute__((always_inline)) {
 #pragma unroll
     for (int g = 0; g < NQ; ++g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[g][r] = __builtin_amdgcn_exp2f(st[g][r]);
+      hs[g] = f32x2_t{st[g][0], st[g][1]};
 #pragma unroll
-      for (int r = 0; r < 8; ++r) lsum2[g] += f32x2_t{st[g][2 * r], st[g][2 * r + 1]};   // v_pk_add_f32
+      for (int r = 1; r < 8; ++r) hs[g] += f32x2_t{st[g][2 * r], st[g][2 * r + 1]};   // v_pk_add_f32
     }
+  };
+  auto pack_pv = [&](f32x16_t (&st)[NQ], const f32x2_t (&hs)[NQ], int so, int kt, int t) __attribute__((always_inline)) {
+#pragma unroll
+    for (int g = 0; g < NQ; ++g) lsum2[g] += hs[g];
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
       bf16x8_t pf[NQ];
@@ -256,6 +264,44 @@ __global__ __launch_bounds__(256, NQ == 2 ? (D == 64 ? 2 : 1) : ((D == 64) ? 3 :
       }
     }
   };
+  // One half step.  `next` issues the S^T chain that runs under this half's exp2 / P.V (the software pipeline).
+  //  * classic (a row may still be without a frame, or the tile carries masks): scale, masks, per-lane maximum (v_max3 chains),
+  //    frame check, then exp2;
+  //  * LIGHT (round 5; interior tiles once every row has met a key): no maximum at all — the scores are scaled into the frame and
+  //    exponentiated at once, and the check is made on what the half step needs anyway, the lane's SUM of its 16 probabilities:
+  //    sum <= LIGHT_BIG means every probability is <= 2^10 (fp32 sums and bf16 P are indifferent to that) — nothing has touched O
+  //    or l yet, so a wave in which some lane fails the check simply recomputes the half's raw scores (4 LDS reads + 4 MFMAs) and
+  //    takes the classic path, which moves the frame.  A score that exceeds its frame by more than 10 bits is as rare as one that
+  //    exceeds it by FRAME_THR = 6 was (the frame is a running maximum); the 9 v_max3 / v_max per half step were 14 % of the loop's
+  //    vector instructions in a loop that is issue-bound.
+  constexpr float LIGHT_BIG = 1024.0f;
+  auto half_step = [&](f32x16_t (&st)[NQ], int so, int kt, int t, auto masked_c, auto&& next) __attribute__((always_inline)) {
+    f32x2_t hs[NQ];
+    bool light = LC2IS_ATTN_LIGHT && !decltype(masked_c)::value && (kt > 0 || t > 0);   // wave-uniform
+#pragma unroll
+    for (int g = 0; g < NQ; ++g) light = light && __all(counted[g]);
+    if (light) {
+#pragma unroll
+      for (int g = 0; g < NQ; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[g][r] = __builtin_fmaf(st[g][r], p.scale_log2, -m_ref[g]);
+      next();
+      exp_sum(st, hs);
+      bool bad = false;
+#pragma unroll
+      for (int g = 0; g < NQ; ++g) bad = bad || !(hs[g][0] + hs[g][1] <= LIGHT_BIG);   // (also catches inf / NaN)
+      if (__any(bad)) {   // rare: some score outgrew its frame by more than 10 bits
+        issue_s(so, t, st);
+        frame(st, kt, t, masked_c);
+        exp_sum(st, hs);
+      }
+    } else {
+      frame(st, kt, t, masked_c);
+      next();
+      exp_sum(st, hs);
+    }
+    pack_pv(st, hs, so, kt, t);
+  };
   auto land = [&]() __attribute__((always_inline)) {   // this wave's outstanding DMAs have landed, and behind the barrier so have every wave's
     wait_vm0();
     __builtin_amdgcn_s_barrier();
@@ -279,20 +325,18 @@ __global__ __launch_bounds__(256, NQ == 2 ? (D == 64 ? 2 : 1) : ((D == 64) ? 3 :
       const bool more = decltype(more_c)::value || kt + 1 < nkt;
       // a ragged last tile with at most 32 keys (S = 64 n + 1): its second half holds nothing (wave-uniform; never on interior tiles)
       const bool h1 = !decltype(masked_c)::value || kt * 64 + 32 < p.Sk;
-      if (wave_active) {
-        frame(sa, kt, 0, masked_c);
-        if (h1) issue_s(so, 1, sb);           // second half of this tile, under the exp2 / P.V of the first
-        finish(sa, so, kt, 0);
-      }
+      if (wave_active)
+        half_step(sa, so, kt, 0, masked_c, [&]() __attribute__((always_inline)) {
+          if (h1) issue_s(so, 1, sb);           // second half of this tile, under the exp2 / P.V of the first
+        });
       if (more) {
         land();
         if (kt + 2 < nkt) request(kt + 2, sreq);
       }
-      if (wave_active && h1) {
-        frame(sb, kt, 1, masked_c);
-        if (more) issue_s(son, 0, sa);        // first half of the next tile, under the exp2 / P.V of this one
-        finish(sb, so, kt, 1);
-      }
+      if (wave_active && h1)
+        half_step(sb, so, kt, 1, masked_c, [&]() __attribute__((always_inline)) {
+          if (more) issue_s(son, 0, sa);        // first half of the next tile, under the exp2 / P.V of this one
+        });
     };
     if (nkt > 0) {
       land();
@@ -316,13 +360,10 @@ __global__ __launch_bounds__(256, NQ == 2 ? (D == 64 ? 2 : 1) : ((D == 64) ? 3 :
       const bool h1 = !decltype(masked_c)::value || kt * 64 + 32 < p.Sk;
       if (wave_active) {
         issue_s(so, 0, sa);
-        frame(sa, kt, 0, masked_c);
-        if (h1) issue_s(so, 1, sb);
-        finish(sa, so, kt, 0);
-        if (h1) {
-          frame(sb, kt, 1, masked_c);
-          finish(sb, so, kt, 1);
-        }
+        half_step(sa, so, kt, 0, masked_c, [&]() __attribute__((always_inline)) {
+          if (h1) issue_s(so, 1, sb);
+        });
+        if (h1) half_step(sb, so, kt, 1, masked_c, [&]() __attribute__((always_inline)) {});
       }
     };
     const std::true_type yes;

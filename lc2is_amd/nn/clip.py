@@ -156,12 +156,14 @@ def _stack_shadows(stack: _Stack, a: ClipArch, device):
     return per, entries
 
 
-# The residual stream of the towers (round 5, LC2IS_RESID_STREAM=bf16|f32): in bf16 the two residual joins of a layer are
-# `bf16(acc + bias + x)` epilogues (fp32 add, ONE rounding; LC2IS_ACT_ADD_AUX) that read 2 and write 2 bytes per element instead of
-# 4 + 4, LayerNorm reads 2 instead of 4 (forward and backward), and the saved x / x_mid halve.  Cost: the stream is rounded to 8
-# significant bits at each of the 2 x layers joins; what that does to the logits and the gradients is measured by the full-depth
-# gates of tests/test_gpu_parity2.py.
-_RESID_BF16 = __import__('os').environ.get("LC2IS_RESID_STREAM", "bf16") != "f32"
+# The residual stream of the towers: fp32 (default) or bf16 (LC2IS_RESID_STREAM=bf16, round 5).  In bf16 the two residual joins of
+# a layer are `bf16(acc + bias + x)` epilogues (fp32 add, ONE rounding; LC2IS_ACT_ADD_AUX) that read 2 and write 2 bytes per element
+# instead of 4 + 4, LayerNorm reads 2 instead of 4 (forward and backward), and the saved x / x_mid halve: +1.3 % images/s on the
+# headline step (profiles/r05_bench_ab_resid_stream.txt).  It stays OPT-IN because the stream is then rounded to 8 significant bits at
+# each of the 2 x layers joins, and every parity margin pays for it (profiles/r05_parity_resid_stream.txt): config-2 logits rel-L2
+# 6.4e-3 -> 9.8e-3, the ViT tower's error at depth 12 3.1e-3 -> 8.9e-3, config 4 at its 24 layers 6.6e-3 -> 1.26e-2 (bound 1.3e-2), and
+# the decoder's `linear1` gradient (relu masks that flip on noisier inputs) 3.9e-2 -> 9.2e-2, past the stated 8e-2 — parity comes first.
+_RESID_BF16 = __import__('os').environ.get("LC2IS_RESID_STREAM", "f32") == "bf16"
 
 
 def _stack_fwd(x, stack: _Stack, sh, a: ClipArch, B: int, S: int, kbias, causal: bool, save: bool):

@@ -91,6 +91,45 @@ def test_attention_fwd_spiked_scores(dev):
     assert (o.double() - ro).abs().max().item() < 3e-2
 
 
+@pytest.mark.parametrize("bits", [5.0, 7.0, 9.5, 10.5, 14.0, 60.0, 140.0, 400.0])
+@pytest.mark.parametrize("key", [40, 70, 96 + 64 * 5, 1000])
+def test_attention_fwd_frame_growth_by_chosen_bits(dev, bits, key):
+    """Round 5: interior half steps check the lane's SUM of probabilities (<= 2^10) instead of a per-score maximum; a half whose
+    sum fails is recomputed on the classic path, which moves the row's frame.  One key is made to score `bits` (log2 units) above
+    everything a chosen query has seen — below the old threshold (6), between the old and the new one (probabilities up to 2^10
+    stay in the frame), just past the new one, and far beyond fp32's exp2 range (inf in the light path) — at a key position in
+    the first tile's second half, in the second tile, in a late tile of the unrolled loop and in the rolled tail.  Output and
+    log-sum-exp against fp64 on the full tensor; the backward runs on the result (its LSE comes from here)."""
+    from lc2is_amd import ops
+    B, H, S, D = 2, 2, 1025, 64
+    g = torch.Generator(device="cpu").manual_seed(int(bits * 10) + key)
+    q = torch.randn(B * S, H * D, generator=g)
+    k = torch.randn(B * S, H * D, generator=g)
+    v = torch.randn(B * S, H * D, generator=g)
+    scale = 0.125
+    for b in range(B):
+        for h in range(H):
+            qi = 100 + 37 * h + b          # the query that meets the spike
+            qv = q[b * S + qi, h * D:(h + 1) * D]
+            base = (q[b * S + qi, h * D:(h + 1) * D] @ k[b * S:(b + 1) * S, h * D:(h + 1) * D].T * scale * 1.4426950408889634).max().item()
+            a = (base + bits) / (qv @ qv * scale * 1.4426950408889634).item()
+            k[b * S + key, h * D:(h + 1) * D] = qv * a
+    q, k, v = (t.to(torch.bfloat16).to(dev) for t in (q, k, v))
+    o, lse2 = ops.attention_fwd(q, k, v, B, H, S, S, D, scale)
+    assert torch.isfinite(o.float()).all() and torch.isfinite(lse2).all()
+    qd, kd, vd = (t.double().clone().requires_grad_(True) for t in (q, k, v))
+    ro, rlse, _ = _ref_attention(qd, kd, vd, B, H, S, S, D, scale, False, None)
+    assert (o.double() - ro.detach()).abs().max().item() < 3e-2
+    assert ((o.double() - ro.detach()).norm() / ro.detach().norm()).item() < 6e-3
+    assert (lse2.double() * math.log(2.0) - rlse.detach()).abs().max().item() < 2e-2
+    do = torch.randn(B * S, H * D, generator=g).to(torch.bfloat16).to(dev)
+    dq, dk, dv = ops.attention_bwd(q, k, v, o, do, lse2, B, H, S, S, D, scale)
+    ro.backward(do.double())
+    for name, got, ref in (("dq", dq, qd.grad), ("dk", dk, kd.grad), ("dv", dv, vd.grad)):
+        rel = ((got.double() - ref).norm() / ref.norm().clamp_min(1e-30)).item()
+        assert rel < 3e-2, (name, rel)
+
+
 @pytest.mark.parametrize("causal", [False, True])
 def test_attention_very_negative_first_keys(dev, causal):
     """A row whose FIRST half tile scores far below -128 in log2 units (q = +8, k[:64] = -8 at D = 64, scale 1: -4096):

@@ -375,7 +375,8 @@ def test_config4_full_depth_forward_and_loss_vs_oracle(dev):
 
 # measured (round 4): logits rel-L2 6.6e-3, argmax agreement 0.9915 (random weights), loss 17.1838 vs 17.1778.  Bounds = measured x 2.
 CFG4_D24_LOGITS_MAX, CFG4_D24_LOSS_MAX = 1.3e-2, 1.2e-2
-CFG4_D24_GRAD_MAX = 6e-2   # (round 5: first run; restated as measured x 2 once profiles/r05_parity.json holds the numbers)
+# round 5: the eleven gradients at depth 24 measure 0.60e-2 .. 1.45e-2 (profiles/r05_parity.json).  Bound = worst x 2.
+CFG4_D24_GRAD_MAX = 3e-2
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -10,9 +10,10 @@ import json
 import re
 import sys
 
-FAMILIES = ["gemm_nt_pp_kernel", "gemm_nt_w384_kernel", "gemm_nt_rows_kernel", "gemm_nt_persist2_kernel", "gemm_nt_dma_kernel", "gemm_nt_kernel", "gemm_tn_grouped_tbl_kernel",
+FAMILIES = ["gemm_nt_pp_kernel", "gemm_nt_w384_kernel", "gemm_nt_rows_kernel", "gemm_nt_dma_kernel", "gemm_nt_kernel", "gemm_tn_grouped_tbl_kernel",
             "gemm_tn_grouped_kernel", "gemm_tn_dma_kernel", "gemm_tn_kernel", "attn_fwd_kernel", "attn_bwd_dq2_kernel",
-            "attn_bwd_dkdv_kernel", "attn_bwd_fused_kernel", "ln_fwd_kernel", "ln_bwd_kernel", "head_ce_grp_kernel", "sgd_kernel"]
+            "attn_bwd_dkdv_kernel", "ln_fwd_kernel", "ln_bwd_kernel", "head_ce_grp_kernel", "head_finish_kernel", "sgd_kernel",
+            "bilinear_up_fwd_kernel", "bilinear_up_bwd_kernel", "add_n_kernel", "sr_gather_kernel", "sr_scatter_add_kernel", "l2norm_fwd_kernel", "l2norm_bwd_kernel"]
 
 
 def short(k):
