@@ -5,14 +5,15 @@
 #   beside --pmc; the program directly after `--`), then tools/hbm_table.py -> gpurun_out/<tag>_hbm_table.txt
 tag=$1; n=$2; shift 2
 root=${GRAFT_REPO_ROOT:-/root/repo}
+script=$root/$1; shift   # (the runs start in /tmp: the script path is taken relative to the repository)
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $root/gpurun_out/prof_${tag}_t -o p --output-format csv -- python3 "$@" > $root/gpurun_out/${tag}_trace.log 2>&1 || { tail -5 $root/gpurun_out/${tag}_trace.log; exit 1; }
+rocprofv3 --kernel-trace --stats -d $root/gpurun_out/prof_${tag}_t -o p --output-format csv -- python3 $script "$@" > $root/gpurun_out/${tag}_trace.log 2>&1 || { tail -5 $root/gpurun_out/${tag}_trace.log; exit 1; }
 for c in FETCH_SIZE WRITE_SIZE; do
   d=$(echo $c | tr A-Z a-z | sed 's/_size//')
-  rocprofv3 --pmc $c --kernel-trace -d $root/gpurun_out/prof_${tag}_$d -o f --output-format csv -- python3 "$@" > $root/gpurun_out/${tag}_$d.log 2>&1 || { tail -5 $root/gpurun_out/${tag}_$d.log; exit 1; }
+  rocprofv3 --pmc $c --kernel-trace -d $root/gpurun_out/prof_${tag}_$d -o f --output-format csv -- python3 $script "$@" > $root/gpurun_out/${tag}_$d.log 2>&1 || { tail -5 $root/gpurun_out/${tag}_$d.log; exit 1; }
 done
 python3 $root/tools/hbm_table.py $root/gpurun_out/prof_${tag}_t/p_kernel_stats.csv $root/gpurun_out/prof_${tag}_fetch/f_counter_collection.csv \
-  $root/gpurun_out/prof_${tag}_write/f_counter_collection.csv $n "$*" > $root/gpurun_out/${tag}_hbm_table.txt
+  $root/gpurun_out/prof_${tag}_write/f_counter_collection.csv $n "$script $*" > $root/gpurun_out/${tag}_hbm_table.txt
 cp $root/gpurun_out/prof_${tag}_t/p_kernel_stats.csv $root/gpurun_out/${tag}_kernel_stats.csv
 tail -1 $root/gpurun_out/${tag}_trace.log | cut -c1-400
 cat $root/gpurun_out/${tag}_hbm_table.txt

@@ -4,6 +4,7 @@
 # usage (GPU box): bash tools/prof_sq.sh <tag> [script and args: default bench.py --steps 2 --warmup 1 --no-cpu-baseline]   -> gpurun_out/sq_<tag>.txt (+ .json)
 tag=${1:-x}
 shift
+if [ $# -gt 0 ]; then set -- $GRAFT_REPO_ROOT/"$@"; fi   # (the runs start in /tmp: a script path is taken relative to the repository)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 i=0
