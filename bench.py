@@ -55,7 +55,7 @@ SAMPLE_EVERY = 4   # HIP-event pairs around the dominant kernel on every 4th tim
 class GemmTimer:
     """HIP-event timing of every call that runs the dominant kernel — the large-tile LDS-DMA NT GEMM (gemm_nt_dma_kernel<256,256,2,4>,
     its persistent forms gemm_nt_persist2_kernel / gemm_nt_pp_kernel and the 256x384 form gemm_nt_w384_kernel, same tile algebra), i.e. the NT GEMMs
-    with >= 1024 128x128 tiles of output and N % 256 == 0 (the dispatch rule of lc2is_gemm_nt_bf16) — recorded on the
+    with >= 1024 128x128 tiles (or >= 224 256x256 tiles) of output and N % 256 == 0 (the dispatch rule of lc2is_gemm_nt_bf16) — recorded on the
     stream the kernel is launched on.  (The small GEMMs of the text tower / decoder use other tile kernels and overlap
     the vision tower on a side stream; they are not part of this kernel's roofline.)"""
 
@@ -72,8 +72,8 @@ class GemmTimer:
 
         def timed(a, w, bias=None, **kw):
             M, N = a.shape[0], w.shape[0]
-            if ((M + 127) // 128) * ((N + 127) // 128) < 1024 or N % 256 or kw.get("tile_cfg", 0) or _NO_TIMER \
-                    or not self.active:
+            big = ((M + 127) // 128) * ((N + 127) // 128) >= 1024 or ((M + 255) // 256) * (N // 256) >= 224   # lc2is_gemm_nt_bf16's rule
+            if not big or N % 256 or kw.get("tile_cfg", 0) or _NO_TIMER or not self.active:
                 return orig(a, w, bias, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()

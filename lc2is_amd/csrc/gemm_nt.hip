@@ -893,7 +893,7 @@ __device__ __forceinline__ bf16x8_t lds_read_b128(unsigned addr) {   // by 32-bi
 }
 
 template <int ACT>
-__global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmNtArgs p, int ntiles, int stagger) {
+__global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmNtArgs p, int ntiles) {
   constexpr int BM = 256, BN = 256, WAVES_N = 4, BK = 64;
   constexpr int WM = 128, WN = 64, TM = 8, TN = 4;
   constexpr int STAGE = (BM + BN) * 128;
@@ -944,20 +944,6 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmNtArgs p, int ntile
   };
 
   int t = blockIdx.x;
-  if (stagger > 0 && gridDim.x == 256) {
-    // DE-SYNCHRONISED ROUNDS (round 5).  With every CU starting together, all 256 blocks reach their epilogues together: the
-    // matrix pipes idle while the chip's HBM write rate (not a CU's: 27 against 108 GB/s per CU, r03_store_overlap_probe) sets
-    // the epilogue's length, then HBM idles while everybody is in the K loop.  Block b starts `vb / 256 x stagger` late (vb:
-    // b with the 5 bits of its in-XCD index reversed — neighbours in launch order get far-apart delays, b % 8 = the XCD label
-    // xcd_remap relies on is kept) and walks tiles vb, vb + 256, ...: the blocks that take the extra tile of a ragged last round
-    // are the ones that started first.  Epilogues of some CUs then run under the K loops of the others.
-    const unsigned b = blockIdx.x;
-    const unsigned vb = ((__brev(b >> 3) >> 27) << 3) | (b & 7);
-    t = (int)vb;
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
-    const unsigned long long wait = (unsigned long long)vb * (unsigned)stagger / 256u;
-    while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
-  }
   if (t >= ntiles) return;
   tile_offsets(t, lane0);
   if (wm == 1) issue_w(0);
@@ -1061,9 +1047,7 @@ int launch_pp_act(const GemmNtArgs& a, hipStream_t stream) {
   }
   const int ntiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
   const int grid = ntiles < lc2is_ncu() ? ntiles : lc2is_ncu();   // one block per CU of the budget (common.h)
-  const char* sg = getenv("LC2IS_GEMM_STAGGER_NS");   // (experiment: re-read per launch so that one process can A/B it)
-  const int stagger = sg ? atoi(sg) / 10 : 0;          // 100 MHz ticks
-  hipLaunchKernelGGL(gemm_nt_pp_kernel<ACT>, dim3(grid), dim3(512), LDS, stream, a, ntiles, stagger);
+  hipLaunchKernelGGL(gemm_nt_pp_kernel<ACT>, dim3(grid), dim3(512), LDS, stream, a, ntiles);
   return lc2is_check_launch();
 }
 
@@ -1236,7 +1220,12 @@ extern "C" int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw
   static const bool fold_tail = tail_cfg == 17 && !(getenv("LC2IS_GEMM_TAIL_FOLD") && atoi(getenv("LC2IS_GEMM_TAIL_FOLD")) == 0);
   const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
   static const long cfg6_min = getenv("LC2IS_GEMM_CFG6_MIN") ? atol(getenv("LC2IS_GEMM_CFG6_MIN")) : 128;   // (512 and the register-staged 128x128 kernel below it measured 0.8 % slower on config 5)
-  if (!(tiles128 >= 1024 && N % 256 == 0)) {
+  // The large-tile (256-row) family takes a problem from about one round of 256x256 tiles on: >= 1024 tiles of 128x128, or (round 5)
+  // >= 7/8 of a round of 256x256 tiles — ViT-L/14 at B = 8 (M = 16 208, N = 1024: 127 x 8 = 1016 small tiles, 64 x 4 = 256 large ones,
+  // exactly ONE round) sat a hair under the first rule and ran its N = 1024 GEMMs on 128x128 tiles at 379 TF/s (profiles/r05_config4_*).
+  static const long big_min256 = getenv("LC2IS_GEMM_BIG_MIN256") ? atol(getenv("LC2IS_GEMM_BIG_MIN256")) : 224;
+  const long tiles256 = (long)((M + 255) / 256) * (N / 256);
+  if (!((tiles128 >= 1024 || tiles256 >= big_min256) && N % 256 == 0)) {
     if (tiles128 >= cfg6_min) cfg = 6;              // 128x128 LDS-DMA tiles, 2 blocks/CU
     else if (tiles128 >= 128) cfg = 1;
     else cfg = 3;                                        // small problem: 64x64 tiles to fill the chip
