@@ -245,7 +245,18 @@ def main():
             except OSError:
                 rccl_log = None
         if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            # RCCL's collectives run on a stream torch takes from its pool; HIP maps streams onto a few hardware queues and two
+            # streams on one queue run IN ORDER — a normal-priority pool stream can land on the compute stream's queue, and the
+            # all-reduce of one bucket would then hold back the backward kernels enqueued behind it (found on one GPU with the text
+            # tower's side stream: profiles/r05_dp_one_gpu.txt).  High-priority streams have queues of their own.
+            kw = {}
+            try:
+                opts = dist.ProcessGroupNCCL.Options()
+                opts.is_high_priority_stream = True
+                kw = {"pg_options": opts}
+            except (AttributeError, TypeError):
+                pass
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, **kw)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 

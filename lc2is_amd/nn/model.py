@@ -203,7 +203,14 @@ class BaseModelWithText(HipModule):
             dev = text_inputs["input_ids"].device
             main = torch.cuda.current_stream(dev)
             if self._text_stream is None or self._text_stream.device != dev:
-                self._text_stream = torch.cuda.Stream(dev)
+                # HIGH priority (round 5): HIP multiplexes streams onto a few hardware queues, and two streams on one queue run
+                # in order.  Which queue a pool stream lands on depends on what else created streams before it — with a
+                # process group on `nccl` the side stream of this class shared the main stream's queue and the tower ran
+                # SERIALISED (34.0 instead of 30.7 ms per step, profiles/r05_dp_one_gpu.txt).  Priority levels have queues of
+                # their own, so a high-priority stream never shares one with the (normal-priority) stream the vision tower is on;
+                # its launches are tiny and few CUs wide.  LC2IS_TEXT_STREAM_PRIO=0: a normal-priority pool stream as before.
+                prio = int(__import__("os").environ.get("LC2IS_TEXT_STREAM_PRIO", "-1"))
+                self._text_stream = torch.cuda.Stream(dev, priority=prio)
             side = self._text_stream
             side.wait_stream(main)
             with torch.cuda.stream(side):

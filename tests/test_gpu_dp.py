@@ -187,7 +187,9 @@ def _rccl_one_rank_worker(port, out_path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dev = torch.device("cuda", 0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    opts = dist.ProcessGroupNCCL.Options()
+    opts.is_high_priority_stream = True            # as bench.py creates it (collectives on a hardware queue of their own)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, pg_options=opts)
     torch.cuda.set_device(dev)
     from lc2is_amd.dp import GradReducer
     from lc2is_amd.step import TrainStep

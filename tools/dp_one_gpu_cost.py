@@ -32,7 +32,9 @@ def main():
     os.environ.setdefault("MASTER_PORT", str(29300 + os.getpid() % 100))
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    opts = dist.ProcessGroupNCCL.Options()
+    opts.is_high_priority_stream = True            # as bench.py creates it
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, pg_options=opts)
     import bench
     import lc2is_amd.nn as N
     from lc2is_amd.dp import GradReducer
