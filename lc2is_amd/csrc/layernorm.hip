@@ -8,6 +8,7 @@
 //           final_layer_norm (hf CLIPTextModel), norm1-3 of model/decoder.py:9 DecoderLayer.
 #include "common.h"
 #include "lc2is_hip.h"
+#include <cstdlib>
 
 namespace {
 
@@ -208,6 +209,113 @@ __global__ __launch_bounds__(256, (NV <= 3 ? LN_BWD_OCC : NV == 4 ? 3 : NV <= 6 
   }
 }
 
+// LEAN form for the towers' backward (round 5): dy, dres and the output are bf16 (the bf16 gradient stream), x fp32 or bf16.  Same
+// arithmetic per element as ln_bwd_kernel (bitwise the same outputs); what differs is the memory side: a bf16 stream moves 8 bytes per
+// lane and instruction, so the generic kernel — one row per wave in flight, 4 waves per SIMD — kept too few bytes in flight once the
+// fp32 streams were gone (10 bytes per element at 3.9 TB/s where the 16-byte form ran 5.5).  Here the NEXT row's loads are requested
+// before the current row's reductions (raw packed words: 8 registers per float4 group) and the kernel is compiled for 3 waves per SIMD.
+template <int NV, bool XB>
+__global__ __launch_bounds__(256, (NV <= 3 ? 3 : NV == 4 ? 2 : 1)) void ln_bwd_lean_kernel(const bf16_t* __restrict__ dyb, int lddy,
+                                                      const void* __restrict__ xv_, int ldx,
+                                                      const float* __restrict__ gamma,
+                                                      const float* __restrict__ mean,
+                                                      const float* __restrict__ rstd,
+                                                      const bf16_t* __restrict__ dresb, int lddres,
+                                                      bf16_t* dxb, int lddxb, float* ws, int nparts, int M, int C) {
+  __shared__ float red[4 * 2048];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int C4 = C >> 2;
+  // the workspace holds `nparts` rows of partials (the generic kernel's block count: the callers size and reduce it by that); this
+  // grid is smaller (one resident round at 3 waves per SIMD), so the rows it does not own are written as zeros
+  for (int rz = gridDim.x + blockIdx.x; rz < nparts; rz += gridDim.x)
+    for (int c = threadIdx.x; c < 2 * C; c += 256) ws[(size_t)rz * 2 * C + c] = 0.f;
+  float4 gm[NV], dg[NV], db[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c4 = lane + 64 * i;
+    gm[i] = (c4 < C4) ? reinterpret_cast<const float4*>(gamma)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    dg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  struct Raw { uint2 dy[NV], rv[NV]; f32x4_t xf[XB ? 1 : NV]; uint2 xb[XB ? NV : 1]; };
+  auto load_row = [&](int row, Raw& r) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c4 = lane + 64 * i;
+      const bool ok = c4 < C4;
+      r.rv[i] = (dresb && ok) ? *reinterpret_cast<const uint2*>(dresb + (size_t)row * lddres + 4 * c4) : make_uint2(0u, 0u);
+      r.dy[i] = ok ? *reinterpret_cast<const uint2*>(dyb + (size_t)row * lddy + 4 * c4) : make_uint2(0u, 0u);
+      if constexpr (XB) r.xb[i] = ok ? *reinterpret_cast<const uint2*>((const bf16_t*)xv_ + (size_t)row * ldx + 4 * c4) : make_uint2(0u, 0u);
+      else r.xf[i] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>((const float*)xv_ + (size_t)row * ldx + 4 * c4))
+                        : f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto widen = [](uint2 pk) {
+    return make_float4(bf16_to_f32((bf16_t)(pk.x & 0xffff)), bf16_to_f32((bf16_t)(pk.x >> 16)),
+                       bf16_to_f32((bf16_t)(pk.y & 0xffff)), bf16_to_f32((bf16_t)(pk.y >> 16)));
+  };
+  const int stride = gridDim.x * 4;
+  int row = blockIdx.x * 4 + wave;
+  Raw cur, nxt;
+  if (row < M) load_row(row, cur);
+  for (; row < M; row += stride) {
+    const bool more = row + stride < M;
+    if (more) load_row(row + stride, nxt);
+    const float mu = mean[row], rs = rstd[row];
+    float4 xh[NV], dy[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c4 = lane + 64 * i;
+      if (c4 < C4) {
+        float4 xv;
+        if constexpr (XB) xv = widen(cur.xb[i]);
+        else xv = make_float4(cur.xf[i][0], cur.xf[i][1], cur.xf[i][2], cur.xf[i][3]);
+        dy[i] = widen(cur.dy[i]);
+        xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+        const float a = dy[i].x * gm[i].x, b = dy[i].y * gm[i].y, c = dy[i].z * gm[i].z, d = dy[i].w * gm[i].w;
+        s1 += (a + b) + (c + d);
+        s2 += (a * xh[i].x + b * xh[i].y) + (c * xh[i].z + d * xh[i].w);
+        dg[i].x += dy[i].x * xh[i].x; dg[i].y += dy[i].y * xh[i].y;
+        dg[i].z += dy[i].z * xh[i].z; dg[i].w += dy[i].w * xh[i].w;
+        db[i].x += dy[i].x; db[i].y += dy[i].y; db[i].z += dy[i].z; db[i].w += dy[i].w;
+      }
+    }
+    const float c1 = wave_sum(s1) / (float)C, c2 = wave_sum(s2) / (float)C;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c4 = lane + 64 * i;
+      if (c4 < C4) {
+        const float4 rv = widen(cur.rv[i]);
+        float4 o;
+        o.x = rs * (dy[i].x * gm[i].x - c1 - xh[i].x * c2);
+        o.y = rs * (dy[i].y * gm[i].y - c1 - xh[i].y * c2);
+        o.z = rs * (dy[i].z * gm[i].z - c1 - xh[i].z * c2);
+        o.w = rs * (dy[i].w * gm[i].w - c1 - xh[i].w * c2);
+        o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+        uint2 pk = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
+        __builtin_nontemporal_store(i32x2_t{(int)pk.x, (int)pk.y}, reinterpret_cast<i32x2_t*>(dxb + (size_t)row * lddxb + 4 * c4));
+      }
+    }
+    if (more) cur = nxt;
+  }
+  float* r = red;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c4 = lane + 64 * i;
+      if (c4 < C4) *reinterpret_cast<float4*>(r + wave * 2048 + 4 * c4) = pass ? db[i] : dg[i];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+      const float t = (r[c] + r[2048 + c]) + (r[4096 + c] + r[6144 + c]);
+      ws[((size_t)blockIdx.x * 2 + pass) * C + c] = t;
+    }
+  }
+}
+
 // out[c] (+)= sum_b ws[b][which][c]; grid over columns
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ ws, int nblk, int C,
                                                              float* dgamma, float* dbeta, int accumulate) {
@@ -284,11 +392,36 @@ extern "C" int lc2is_layernorm_bwd(const void* dy_bf16, int lddy, const float* d
     return LC2IS_ERR_SHAPE;
   if (!workspace || workspace_bytes < lc2is_layernorm_bwd_workspace_bytes(M, C)) return LC2IS_ERR_WORKSPACE;
   const int nblk = ln_bwd_blocks(M, C);
+  const int nv = (C / 4 + 63) / 64;
+  // the towers' path: bf16 dy / dres / output only -> the lean kernel with next-row prefetch (LC2IS_LN_BWD_LEAN=0: the generic one)
+  static const bool lean_on = !(getenv("LC2IS_LN_BWD_LEAN") && atoi(getenv("LC2IS_LN_BWD_LEAN")) == 0);
+  if (lean_on && dy_bf16 && !dy_f32 && !dx_f32 && dx_bf16 && (!dres || dres_is_bf16) && nv <= 4) {
+    const int cap = 256 * (nv <= 2 ? 4 : nv == 3 ? 3 : 2);     // one resident round of 4-wave blocks at the lean kernel's occupancy (116 / 164 / 204 registers)
+    const int lgrid = nblk < cap ? nblk : cap;
+#define LN_LEAN(NV_)                                                                                                       \
+  do {                                                                                                                     \
+    if (x_is_bf16)                                                                                                         \
+      hipLaunchKernelGGL((ln_bwd_lean_kernel<NV_, true>), dim3(lgrid), dim3(256), 0, stream, (const bf16_t*)dy_bf16, lddy, x, \
+                         ldx, gamma, mean, rstd, (const bf16_t*)dres, lddres, (bf16_t*)dx_bf16, lddxb, (float*)workspace, nblk, M, C); \
+    else                                                                                                                   \
+      hipLaunchKernelGGL((ln_bwd_lean_kernel<NV_, false>), dim3(lgrid), dim3(256), 0, stream, (const bf16_t*)dy_bf16, lddy, x, \
+                         ldx, gamma, mean, rstd, (const bf16_t*)dres, lddres, (bf16_t*)dx_bf16, lddxb, (float*)workspace, nblk, M, C); \
+  } while (0)
+    if (nv <= 1) LN_LEAN(1); else if (nv == 2) LN_LEAN(2); else if (nv == 3) LN_LEAN(3); else LN_LEAN(4);
+#undef LN_LEAN
+    int rc = lc2is_check_launch();
+    if (rc) return rc;
+    if (dgamma || dbeta) {
+      hipLaunchKernelGGL(partials_reduce_kernel, dim3((C + 31) / 32, 2), dim3(1024), 0, stream,
+                         (const float*)workspace, nblk, (size_t)2 * C, (size_t)C, C, dgamma, dbeta, accumulate);
+      rc = lc2is_check_launch();
+    }
+    return rc;
+  }
 #define LN_BWD(NV_)                                                                                   \
   hipLaunchKernelGGL(ln_bwd_kernel<NV_>, dim3(nblk), dim3(256), 0, stream, (const bf16_t*)dy_bf16, lddy, \
                      dy_f32, lddyf, xf, xb, ldx, gamma, mean, rstd, dresf, dresb, lddres, dx_f32, lddx,  \
                      (bf16_t*)dx_bf16, lddxb, (float*)workspace, M, C)
-  const int nv = (C / 4 + 63) / 64;
   if (nv <= 1) LN_BWD(1); else if (nv == 2) LN_BWD(2); else if (nv == 3) LN_BWD(3);
   else if (nv == 4) LN_BWD(4); else if (nv <= 6) LN_BWD(6); else LN_BWD(8);
 #undef LN_BWD

@@ -426,6 +426,33 @@ def test_layernorm_bf16_streams(dev, M, C):
     assert dxf3 is None and torch.equal(dxb3, a[1])
 
 
+@pytest.mark.parametrize("M,C", [(32800, 768), (2416, 512), (4100, 1024), (16208, 1024), (333, 64), (3, 768)])
+def test_layernorm_bwd_lean_kernel(dev, M, C):
+    """Round 5: the towers' backward (bf16 dy / residual-path gradient / output) runs a lean kernel with next-row prefetch on a
+    smaller grid.  Same per-element arithmetic as the generic kernel: dx is BITWISE equal to the generic kernel's (reached through
+    the fp32-dres entry with the widened tensor), dgamma / dbeta agree to fp32 summation order, and everything agrees with fp64;
+    x in fp32 and in bf16; with and without a residual-path gradient; more rows than one grid round, fewer rows than a block."""
+    from lc2is_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M + C)
+    x32 = (torch.randn(M, C, generator=g) * 2 + 0.5).to(dev)
+    gamma = (1 + 0.1 * torch.randn(C, generator=g)).to(dev)
+    dyb = _bf(torch.randn(M, C, generator=g).to(dev))
+    dresb = _bf(torch.randn(M, C, generator=g).to(dev))
+    for x in (x32, _bf(x32)):
+        _, _, mean, rstd = ops.layernorm_fwd(x, gamma, None, 1e-5)
+        for dres_lean, dres_gen in ((dresb, dresb.float()), (None, None)):
+            lean = ops.layernorm_bwd(dyb, x, gamma, mean, rstd, dres=dres_lean, want_f32=False)              # lean kernel
+            gen = ops.layernorm_bwd(dyb, x, gamma, mean, rstd, dres=dres_gen, want_f32=True)                  # generic kernel
+            assert lean[0] is None and torch.equal(lean[1], gen[1])
+            assert _rel(lean[2], gen[2]) < 2e-6 and _rel(lean[3], gen[3]) < 2e-6
+        xd = x.double().requires_grad_(True)
+        gd = gamma.double().requires_grad_(True)
+        torch.nn.functional.layer_norm(xd, (C,), gd, None, 1e-5).backward(dyb.double())
+        dxb, dg = ops.layernorm_bwd(dyb, x, gamma, mean, rstd, dres=dresb, want_f32=False)[1:3]
+        assert _rel(dxb.float(), xd.grad + dresb.double()) < 4e-3
+        assert _rel(dg, gd.grad) < 1e-5
+
+
 def test_layernorm_bwd_deferred_param_grads_are_bitwise_equal(dev):
     """The dgamma / dbeta reductions of several LayerNorm backward calls in one grouped launch (ops.ln_defer_begin/flush,
     opened by nn.base.WgradBatch): same fixed-order sums as the per-call second launch, incl. accumulate and a vector that
