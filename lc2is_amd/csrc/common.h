@@ -34,8 +34,18 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   return __builtin_bit_cast(bf16_t, b);
 }
 
+// two floats -> one dword of two bf16 (lo in bits 0..15).  As a 2-vector conversion hipcc emits ONE v_cvt_pk_bf16_f32; the scalar
+// form `f32_to_bf16(lo) | f32_to_bf16(hi) << 16` it compiled to two of them (one useful half each) plus a v_or_b32_sdwa — three
+// vector instructions per pair in every bf16 epilogue (round 5: 396 -> 132 of the ~1300 in the fc1 epilogue).  Same rounding
+// (nearest-even, NaN stays NaN): bitwise the same outputs.
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+#if defined(LC2IS_OLD_PACK)   // (A/B builds only)
   return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+#endif
+  typedef float f32x2_v __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_v __attribute__((ext_vector_type(2)));
+  const f32x2_v v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_v));
 }
 
 // 128-bit buffer resource over [base, base+bytes): out-of-range loads return 0,

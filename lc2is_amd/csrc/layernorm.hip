@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256, (NV <= 3 ? LN_BWD_OCC : NV == 4 ? 3 : NV <= 6 
 }
 
 // LEAN form for the towers' backward (round 5): dy, dres and the output are bf16 (the bf16 gradient stream), x fp32 or bf16.  Same
-// arithmetic per element as ln_bwd_kernel (bitwise the same outputs); what differs is the memory side: a bf16 stream moves 8 bytes per
+// formulas per element as ln_bwd_kernel (outputs equal up to hipcc's choice of fused multiply-adds); what differs is the memory side: a bf16 stream moves 8 bytes per
 // lane and instruction, so the generic kernel — one row per wave in flight, 4 waves per SIMD — kept too few bytes in flight once the
 // fp32 streams were gone (10 bytes per element at 3.9 TB/s where the 16-byte form ran 5.5).  Here the NEXT row's loads are requested
 // before the current row's reductions (raw packed words: 8 registers per float4 group) and the kernel is compiled for 3 waves per SIMD.
