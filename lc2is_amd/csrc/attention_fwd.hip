@@ -59,30 +59,10 @@ struct AttnFwdArgs {
 // torch:nn/functional.py:6206): l sums the UNDROPPED probabilities, O accumulates keep * P / (1 - p);
 // coordinate of a score = (row (b*H + h)*Sq + q, column key), so the backward kernels regenerate the same decisions.
 constexpr float FRAME_THR = 6.0f;
-#ifndef LC2IS_ATTN_SCALAR_VALU
-#define LC2IS_ATTN_SCALAR_VALU 1   // 1: the per-score fma / row-sum adds as single v_fma_f32 / v_add_f32 (asm); 0: left to hipcc, which SLP-packs them into v_pk_*_f32
-#endif
-// hipcc packs adjacent f32 multiply-adds / adds into v_pk_fma_f32 / v_pk_add_f32.  Beside MFMAs a packed op costs more issue time than the
-// two scalar ops it replaces (MI355X_MICROARCH.md, price of one filler beside MFMAs: 1 v_pk_fma_f32 = 2 v_fma_f32 + 22 cycles), and this
-// loop is issue-bound: the hot per-score ops are pinned to their scalar forms.
-__device__ __forceinline__ float fma_neg_c(float a, float b, float c) {   // a * b - c in ONE v_fma_f32
-#if LC2IS_ATTN_SCALAR_VALU
-  float d;
-  asm("v_fma_f32 %0, %1, %2, -%3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-  return d;
-#else
-  return __builtin_fmaf(a, b, -c);
-#endif
-}
-__device__ __forceinline__ float add_s(float a, float b) {
-#if LC2IS_ATTN_SCALAR_VALU
-  float d;
-  asm("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-  return d;
-#else
-  return a + b;
-#endif
-}
+// (round 5, tried and removed: the per-score fma and the row-sum adds pinned to single v_fma_f32 / v_add_f32 through inline asm
+//  instead of hipcc's v_pk_fma_f32 / v_pk_add_f32 — 137 vs 139 us at the ViT shape, 124 vs 120 at the decoder's, nothing in the step;
+//  and an asm VALU instruction that is the FIRST reader of an MFMA result gets no wait states from hipcc: the D = 96 instantiation
+//  computed garbage.  profiles/r05_attn_fwd_scalar_valu_ab.txt)
 
 // NQ = 32-query groups per wave.  NQ = 1: 3 waves/SIMD at D = 64.  NQ = 2 (64 queries per wave, 256 per block): every K row
 // fragment and every V^T fragment read from LDS feeds TWO MFMA chains (half the LDS bytes per MFMA, and the S^T chains of the two
@@ -202,7 +182,7 @@ __global__ __launch_bounds__(256, NQ == 2 ? (D == 64 ? 2 : 1) : ((D == 64) ? 3 :
     const bool tail = (kt * 64 + 64 > p.Sk);
     const bool diag = p.causal && (kt * 64 + 63 > bx * QB);  // some key may exceed some query
 #pragma unroll
-    for (int r = 0; r < 16; ++r) st[r] = fma_neg_c(st[r], p.scale_log2, m_ref[g]);
+    for (int r = 0; r < 16; ++r) st[r] = __builtin_fmaf(st[r], p.scale_log2, -m_ref[g]);
     if (decltype(masked_c)::value && (tail || diag || p.kbias != nullptr)) {   // key tail / key padding / causal edge: -inf (or the additive key bias) per score
       int key0 = kt * 64 + 32 * t + 4 * hh, qr = qrow[g];
       asm volatile("" : "+v"(key0), "+v"(qr));   // keeps the per-score compares INSIDE this branch (hipcc hoists them otherwise)
@@ -253,16 +233,8 @@ __global__ __launch_bounds__(256, NQ == 2 ? (D == 64 ? 2 : 1) : ((D == 64) ? 3 :
     for (int g = 0; g < NQ; ++g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[g][r] = __builtin_amdgcn_exp2f(st[g][r]);
-#if LC2IS_ATTN_SCALAR_VALU
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        lsum2[g][0] = add_s(lsum2[g][0], st[g][2 * r]);
-        lsum2[g][1] = add_s(lsum2[g][1], st[g][2 * r + 1]);
-      }
-#else
 #pragma unroll
       for (int r = 0; r < 8; ++r) lsum2[g] += f32x2_t{st[g][2 * r], st[g][2 * r + 1]};   // v_pk_add_f32
-#endif
     }
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
