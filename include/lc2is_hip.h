@@ -84,6 +84,20 @@ int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw, const flo
                        float* out_f32, int ldf, void* aux_out, int ldy, int M, int N, int K, int act,
                        int tile_cfg, lc2is_stream_t stream);
 
+/* The residual-stream GEMM and the LayerNorm that follows it in ONE launch (round 5): out_f32 = A.W^T + bias (+ resid) as
+ * lc2is_gemm_nt_bf16 writes it, and ln_out = bf16((out_f32 - mean) * rstd * gamma + beta) per row over the N columns (mean, rstd
+ * fp32 [M], may be NULL).  N = 384 or 768, M >= 256; runs on 256x384 tiles whose two column tiles exchange their row statistics
+ * (two-pass variance, halves combined in a fixed order: reproducible) through `xchg` (>= lc2is_gemm_nt_ln_xchg_bytes, 8-byte
+ * aligned, ALL ZERO before the first call; the kernel leaves it all zero again — one buffer per stream that may run such a launch).
+ * The <= 64 ragged rows of B x 1025-token inputs are computed inside the launch and normalised by a small second launch.
+ * Returns LC2IS_ERR_UNSUPPORTED for shapes it does not take: call lc2is_gemm_nt_bf16 and lc2is_layernorm_fwd instead.
+ * replaces: out_proj / fc2 + residual add followed by layer_norm2 / the next layer's layer_norm1 in hf:CLIPEncoderLayer.forward
+ *   (modeling_clip.py:362-383), reached from model/encoder.py:29-30. */
+size_t lc2is_gemm_nt_ln_xchg_bytes(int M, int N);
+int lc2is_gemm_nt_ln_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, const float* resid, int ldr,
+                          float* out_f32, int ldf, const float* gamma, const float* beta, float eps, void* ln_out, int ldl,
+                          float* mean, float* rstd, void* xchg, size_t xchg_bytes, int M, int N, int K, lc2is_stream_t stream);
+
 /* Strided-batched plain product, ONE launch: for b < batch, out[b][M,N] = A[b][M,K] · W[b][N,K]^T (no bias / activation);
  * stride_* are ELEMENT strides between consecutive problems (stride_a, stride_w multiples of 8, outputs multiples of 4).
  * replaces: torch.einsum('bchw,bkc->bkhw', visual, text) with per-image class embeddings (reference

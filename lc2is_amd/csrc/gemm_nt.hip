@@ -770,7 +770,7 @@ __global__ __launch_bounds__(512) void gemm_nt_w384_kernel(GemmNtArgs p) {
       }
 #pragma unroll
       for (int k = 0; k < 3; ++k)
-        __builtin_amdgcn_raw_buffer_store_b128(*(const i32x4_t*)(patchb + poff[k]), rsB, ooff[k], h * ostep, 0);   // write-back: LayerNorm reads the stream next
+        __builtin_amdgcn_raw_buffer_store_b128(*(const i32x4_t*)(patchb + poff[k]), rsB, ooff[k] + h * ostep, 0, 0);   // write-back: LayerNorm reads the stream next (row step in the vector offset: see EPI = -3)
     }
   } else if constexpr (EPI == 0) {
     // ---- bf16 epilogue: out = bf16(acc + bias), 32 rows x 96 columns of the wave at a time through its LDS patch ----
@@ -805,6 +805,202 @@ __global__ __launch_bounds__(512) void gemm_nt_w384_kernel(GemmNtArgs p) {
         const int b_off = col < p.N ? ((mrow0 + row) * p.ldo + col) * 2 : OOBB;
         __builtin_amdgcn_raw_buffer_store_b128(v, rsB, b_off, 0, 0);   // write-back: the next kernel reads it
       }
+    }
+  } else if constexpr (EPI == -3) {
+    // ---- fp32 epilogue + the LayerNorm that follows it (round 5): x' = acc + bias + resid leaves as fp32 (the residual stream, as
+    // EPI = -2) AND h = LN(x') leaves as bf16 — the next GEMM's operand — without the LayerNorm kernel's pass over x' (read 4, write
+    // 2 bytes per element, 30 us per launch at M = 32 800 x 768, 24 launches per step).  A row's 768 columns live in the
+    // accumulators of 2 x 4 waves of TWO blocks (column tiles tn = 0, 1 of one row tile: consecutive logical tiles, co-resident —
+    // the grid is one round): per row, each block reduces (mean, M2 = sum of squared deviations from ITS mean) over its 384
+    // columns — in registers, across the 4 lanes of a row (g), across the 4 column waves through LDS —, publishes the pair as
+    // two 8-byte {value, tag} granules (one agent-scope store each: the datum is its own flag, no ordering needed), polls the
+    // partner's, and both combine the halves in the fixed order tn = 0, 1 (Chan's update: the two-pass variance of the LayerNorm
+    // kernel, no E[x^2] - mean^2 cancellation): bitwise the same (mean, rstd) on both sides, run to run.  The reader zeroes the
+    // granules it consumed (written once, read once per launch): the exchange buffer is all zero between launches, so a
+    // captured launch replays without a per-launch epoch.  Spins are bounded (a timeout poisons the row with NaN).
+    constexpr int PITCH = WN * 4 + 16;   // 400 B
+    char* patch = smem + wid * (32 * PITCH);
+    float* lnS = (float*)(smem + NWAVE * 32 * PITCH);   // [256][4]: row sums per column wave
+    float* lnQ = lnS + 256 * 4;                         // [256][4]: row sums of squared deviations
+    float* lnF = lnQ + 256 * 4;                         // [256][2]: mean, rstd of the whole row
+    float* lnG = lnF + 256 * 2;                         // [2][384]: gamma, beta of this block's columns
+    const int tn = tile % ntn;
+    if (tid < 192) {   // gamma / beta of the block's 384 columns -> LDS (read back as 16-byte fragments in the MFMA layout)
+      const float* src = tid < 96 ? p.ln_gamma : p.ln_beta;
+      const int c4 = tid < 96 ? tid : tid - 96;
+      f32x4_t v = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      if (src) v = *(const f32x4_t*)(src + n0 + 4 * c4);
+      *(f32x4_t*)(lnG + (tid < 96 ? 0 : 384) + 4 * c4) = v;
+    }
+    const int nw = n0 + wn * WN;
+    const __amdgpu_buffer_rsrc_t rsR = make_rsrc(p.resid, p.resid ? (unsigned)p.M * (unsigned)p.ldr * 4u : 0u);
+    const __amdgpu_buffer_rsrc_t rsO = make_rsrc(p.out_f32, (unsigned)p.M * (unsigned)p.ldf * 4u);
+    // flush mapping of a 32 x 96 fp32 patch: element k * 64 + lane -> (row, 16-byte chunk) of an 8-row block; the 8-row blocks of
+    // the wave's 128 rows are uniform steps (scalar offsets), so a lane keeps three offsets per stream (M is a multiple of 256 here)
+    int r_off[3], o_off[3], p_off[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int e = k * 64 + lane, row = e / 24, ch = e % 24;
+      r_off[k] = ((m0 + wm * WM + row) * p.ldr + nw + ch * 4) * 4;
+      o_off[k] = ((m0 + wm * WM + row) * p.ldf + nw + ch * 4) * 4;
+      p_off[k] = row * PITCH + ch * 16;
+    }
+    const int r_step = 8 * p.ldr * 4, o_step = 8 * p.ldf * 4;
+    // phase A: x' through the wave's patch (EPI = -2's flush), written back to it and read again in the MFMA layout: acc = x'
+#pragma unroll
+    for (int i = 0; i < TN; ++i)   // bias into the accumulators up front: its 24 registers are free for the epilogue
+#pragma unroll
+      for (int j = 0; j < TM; ++j) acc[i][j] += bvs[i];
+#pragma unroll
+    for (int jg = 0; jg < TM / 2; ++jg) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int jl = 0; jl < 2; ++jl)
+          *(f32x4_t*)(patch + (jl * 16 + frow) * PITCH + (i * 16 + g * 4) * 4) = acc[i][jg * 2 + jl];
+#pragma unroll
+      for (int hq = 0; hq < 12; hq += 6) {
+        i32x4_t rv[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          const int rb = jg * 4 + (hq + q) / 3;   // 8-row block of the wave's rows
+          rv[q] = __builtin_amdgcn_raw_buffer_load_b128(rsR, r_off[q % 3], rb * r_step, 0);   // (no residual: zero records, reads as zeros)
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          const int rb = jg * 4 + (hq + q) / 3;
+          f32x4_t* slot = (f32x4_t*)(patch + p_off[q % 3] + ((hq + q) / 3) * 8 * PITCH);
+          const f32x4_t v = *slot + __builtin_bit_cast(f32x4_t, rv[q]);
+          *slot = v;
+          // (row step in the VECTOR offset: with a register in the scalar-offset field hipcc inserts no wait state between a 16-byte
+          //  buffer store and a VALU write of its data registers — LLVM models that case as hazard-free — and on gfx950 the first
+          //  dword of some lanes was stored as the zero a following v_mov_b32 put there: found with this epilogue, round 5)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, v), rsO, o_off[q % 3] + rb * o_step, 0, 0);   // write-back policy
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int jl = 0; jl < 2; ++jl)
+          acc[i][jg * 2 + jl] = *(const f32x4_t*)(patch + (jl * 16 + frow) * PITCH + (i * 16 + g * 4) * 4);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // phase B: per row, sum and squared deviations over the block's 384 columns
+    __builtin_amdgcn_sched_barrier(0);
+    const int rbase = wm * WM + frow;   // the lane's rows in the block: rbase + 16 j
+    float mh[TM];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      float sj = 0.f;
+#pragma unroll
+      for (int i = 0; i < TN; ++i) sj += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
+      sj += __shfl_xor(sj, 16, 64);
+      sj += __shfl_xor(sj, 32, 64);
+      if (g == 0) lnS[(rbase + 16 * j) * 4 + wn] = sj;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const f32x4_t t = *(const f32x4_t*)(lnS + (rbase + 16 * j) * 4);
+      mh[j] = ((t[0] + t[1]) + (t[2] + t[3])) * (1.0f / 384.0f);
+    }
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      float qj = 0.f;
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const f32x4_t d = acc[i][j] - mh[j];
+        qj += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+      }
+      qj += __shfl_xor(qj, 16, 64);
+      qj += __shfl_xor(qj, 32, 64);
+      if (g == 0) lnQ[(rbase + 16 * j) * 4 + wn] = qj;
+    }
+    __syncthreads();
+    // phase C: one thread per row combines the block's pair with the partner block's
+    if (tid < 256) {
+      const int gr = m0 + tid;
+      const f32x4_t s4 = *(const f32x4_t*)(lnS + tid * 4), q4 = *(const f32x4_t*)(lnQ + tid * 4);
+      const float my_mean = ((s4[0] + s4[1]) + (s4[2] + s4[3])) * (1.0f / 384.0f);
+      const float my_m2 = (q4[0] + q4[1]) + (q4[2] + q4[3]);
+      float cm = my_mean, cq = my_m2;
+      if (gr < p.M) {
+        if (ntn == 2) {
+          constexpr unsigned long long TAG = 0x4C4E0001ull << 32;
+          unsigned long long* mine = p.ln_xchg + ((size_t)gr * 2 + tn) * 2;
+          unsigned long long* theirs = p.ln_xchg + ((size_t)gr * 2 + (tn ^ 1)) * 2;
+          __hip_atomic_store(mine, TAG | (unsigned long long)__builtin_bit_cast(unsigned, my_mean), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(mine + 1, TAG | (unsigned long long)__builtin_bit_cast(unsigned, my_m2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          unsigned long long a = 0, b = 0;
+          int spins = 0;
+          for (;;) {
+            a = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            b = __hip_atomic_load(theirs + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (((a & b) >> 32) == (TAG >> 32) || ++spins > (1 << 22)) break;
+            __builtin_amdgcn_s_sleep(2);
+          }
+          float pm = __builtin_bit_cast(float, (unsigned)a), pq = __builtin_bit_cast(float, (unsigned)b);
+          if (((a & b) >> 32) != (TAG >> 32)) pm = pq = __builtin_nanf("");   // the partner never arrived: poison, do not hang
+          __hip_atomic_store(theirs, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(theirs + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          // halves in the order tn = 0, 1 on both sides (equal counts): mean = m0 + (m1 - m0) / 2, M2 = M2_0 + M2_1 + (m1 - m0)^2 * 192
+          const float h0m = tn == 0 ? my_mean : pm, h1m = tn == 0 ? pm : my_mean;
+          const float h0q = tn == 0 ? my_m2 : pq, h1q = tn == 0 ? pq : my_m2;
+          const float dlt = h1m - h0m;
+          cm = h0m + dlt * 0.5f;
+          cq = (h0q + h1q) + dlt * dlt * 192.0f;
+        }
+        const float rstd = rsqrtf(cq / (float)p.N + p.ln_eps);
+        lnF[tid * 2] = cm;
+        lnF[tid * 2 + 1] = rstd;
+        if (tn == 0) {
+          if (p.ln_mean) p.ln_mean[gr] = cm;
+          if (p.ln_rstd) p.ln_rstd[gr] = rstd;
+        }
+      } else {
+        lnF[tid * 2] = 0.f;
+        lnF[tid * 2 + 1] = 0.f;
+      }
+    }
+    __syncthreads();
+    // phase D: h = (x' - mean) * rstd * gamma + beta, bf16, through the wave's patch as whole 192-byte row segments (EPI = 0's flush)
+    constexpr int PITCHB = WN * 2 + 16;   // 208 B
+    char* patchb = patch;                 // (the wave's own region again: 32 x 208 < 32 x 400)
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(p.ln_out, (unsigned)p.M * (unsigned)p.ldl * 2u);
+    int b_off[3], pb_off[3];   // flush mapping of a 32 x 96 bf16 patch: 16 rows x 12 sixteen-byte chunks = 3 wave instructions
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int e = k * 64 + lane, row = e / 12, ch = e % 12;
+      b_off[k] = ((m0 + wm * WM + row) * p.ldl + nw + ch * 8) * 2;
+      pb_off[k] = row * PITCHB + ch * 16;
+    }
+    const int b_step = 16 * p.ldl * 2;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int jg = 0; jg < TM / 2; ++jg) {
+      float mu[2], rs[2];
+#pragma unroll
+      for (int jl = 0; jl < 2; ++jl) {
+        mu[jl] = lnF[(rbase + 16 * (jg * 2 + jl)) * 2];
+        rs[jl] = lnF[(rbase + 16 * (jg * 2 + jl)) * 2 + 1];
+      }
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const f32x4_t gm = *(const f32x4_t*)(lnG + wn * WN + i * 16 + g * 4);
+        const f32x4_t bt = *(const f32x4_t*)(lnG + 384 + wn * WN + i * 16 + g * 4);
+#pragma unroll
+        for (int jl = 0; jl < 2; ++jl) {
+          const f32x4_t v = (acc[i][jg * 2 + jl] - mu[jl]) * rs[jl] * gm + bt;
+          const i32x2_t pk = {(int)pack_bf16x2(v[0], v[1]), (int)pack_bf16x2(v[2], v[3])};
+          *(i32x2_t*)(patchb + (jl * 16 + frow) * PITCHB + (i * 16 + g * 4) * 2) = pk;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const i32x4_t v = *(const i32x4_t*)(patchb + pb_off[q % 3] + (q / 3) * 16 * PITCHB);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rsB, b_off[q % 3] + (jg * 2 + q / 3) * b_step, 0, 0);   // write-back: the next GEMM reads it
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   } else {
   // ---- epilogue: out = acc + bias (+ fp32 residual), 32 rows x 96 columns of the wave at a time through its LDS patch ----
@@ -1314,6 +1510,46 @@ extern "C" int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw
   if (a.out_f32) tail.out_f32 = a.out_f32 + m0 * ldf;
   if (a.aux_out) tail.aux_out = a.aux_out + m0 * ldy;
   return launch_by_cfg(tail, tail_cfg, stream);
+}
+
+// out_f32 = A.W^T + bias (+ resid) AND ln_out = bf16(LayerNorm(out_f32) * gamma + beta) (+ mean / rstd) in ONE launch of the
+// 256x384-tile kernel (EPI = -3: the two column tiles of a row tile exchange their row statistics through `xchg`); N = 384 or 768.
+// The <= 64 ragged rows of B x 1025-token inputs ride in the launch as fragment jobs (fp32 output), their LayerNorm is a second,
+// small launch of the LayerNorm kernel.  LC2IS_ERR_UNSUPPORTED: the caller runs lc2is_gemm_nt_bf16 + lc2is_layernorm_fwd instead.
+extern "C" size_t lc2is_gemm_nt_ln_xchg_bytes(int M, int N) { return N == 768 && M > 0 ? (size_t)M * 32 : 0; }
+
+extern "C" int lc2is_gemm_nt_ln_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, const float* resid,
+                                     int ldr, float* out_f32, int ldf, const float* gamma, const float* beta, float eps,
+                                     void* ln_out, int ldl, float* mean, float* rstd, void* xchg, size_t xchg_bytes, int M,
+                                     int N, int K, lc2is_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!A || !W || !out_f32 || !ln_out || !gamma) return LC2IS_ERR_NULL;
+  if (M <= 0 || N <= 0 || K <= 0) return LC2IS_ERR_SHAPE;
+  if (K % 64 != 0 || lda < K || ldw < K || lda % 8 || ldw % 8) return LC2IS_ERR_SHAPE;
+  if (ldf < N || ldf % 4 || (resid && (ldr < N || ldr % 4)) || ldl < N || ldl % 8) return LC2IS_ERR_SHAPE;
+  if (N != 384 && N != 768) return LC2IS_ERR_UNSUPPORTED;
+  if (M < 256) return LC2IS_ERR_UNSUPPORTED;
+  const double lim = 2147483648.0;
+  if ((double)(M + 256) * lda * 2.0 >= lim || (double)(N + 256) * ldw * 2.0 >= lim || (double)M * ldf * 4.0 >= lim ||
+      (resid && (double)M * ldr * 4.0 >= lim) || (double)M * ldl * 2.0 >= lim)
+    return LC2IS_ERR_UNSUPPORTED;
+  if (N == 768 && (!xchg || xchg_bytes < lc2is_gemm_nt_ln_xchg_bytes(M, N) || ((uintptr_t)xchg & 7))) return LC2IS_ERR_WORKSPACE;
+  const int r = M % 256;
+  if (r > 64) return LC2IS_ERR_UNSUPPORTED;   // (the tiles of the fused form are whole: the ragged rows are at most the 64 the fragment jobs take)
+  const bool peel = r > 0;
+  const int mm = M - r;
+  GemmNtArgs a{(const bf16_t*)A, lda, (const bf16_t*)W, ldw, bias, resid, ldr, nullptr, 0, nullptr, 0, out_f32, ldf, nullptr, 0,
+               mm, N, K, LC2IS_ACT_NONE, 0};
+  a.tail_rows = peel ? r : 0;
+  a.ln_gamma = gamma; a.ln_beta = beta;
+  a.ln_out = (bf16_t*)ln_out; a.ldl = ldl;
+  a.ln_mean = mean; a.ln_rstd = rstd;
+  a.ln_xchg = (unsigned long long*)xchg;
+  a.ln_eps = eps;
+  int rc = launch_w384_epi<-3>(a, stream);
+  if (rc || !peel) return rc;
+  return lc2is_layernorm_fwd(out_f32 + (size_t)mm * ldf, ldf, 0, gamma, beta, (bf16_t*)ln_out + (size_t)mm * ldl, ldl, nullptr, 0,
+                             mean ? mean + mm : nullptr, rstd ? rstd + mm : nullptr, r, N, eps, stream_);
 }
 
 // Strided-batched plain product: out[b] = A[b] (M x K) . W[b]^T (N x K), b = 0..batch-1, in ONE launch (blockIdx.y = b).

@@ -23,6 +23,12 @@ struct GemmNtArgs {
   // ragged rows folded into a large-tile launch (256x384 kernels): rows M .. M + tail_rows - 1 of the same A / output buffers are
   // computed by the blocks' waves after their own tile, one 16 x 16 fragment each (the rows kernel's algorithm, no second launch)
   int tail_rows;
+  // LayerNorm of the fp32 output row fused into the 256x384 kernel's epilogue (EPI = -3, round 5): see gemm_nt_w384_kernel
+  const float* ln_gamma; const float* ln_beta;
+  bf16_t* ln_out; int ldl;
+  float* ln_mean; float* ln_rstd;
+  unsigned long long* ln_xchg;   // M x (N / 384) x 2 eight-byte {value, tag} granules, all zero between launches
+  float ln_eps;
 };
 
 __device__ __forceinline__ float sigmoidf_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }  // v_exp + v_rcp

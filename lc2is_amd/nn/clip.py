@@ -174,21 +174,39 @@ def _stack_fwd(x, stack: _Stack, sh, a: ClipArch, B: int, S: int, kbias, causal:
     scale = D ** -0.5
     saved = []
     lean = x.dtype == torch.bfloat16
-    for layer, s in zip(stack.layers, sh):
-        h, _, m1, r1 = ops.layernorm_fwd(x, layer.layer_norm1.weight, layer.layer_norm1.bias, a.eps, save_stats=save)
+    # round 5: on an fp32 stream the two residual-join GEMMs of a layer also write the LayerNorm that follows them (layer_norm2
+    # behind out-proj, the NEXT layer's layer_norm1 behind fc2) — ops.gemm_nt_ln, one launch instead of two (N = 768 / 384 towers
+    # at >= 4096 rows: the ViT-B vision tower; every other stack keeps the LayerNorm kernel)
+    fuse = (not lean) and ops.gemm_nt_ln_ok(x.shape[0], C, C) and ops.gemm_nt_ln_ok(x.shape[0], C, a.intermediate)
+    nxt_ln = None   # (h, mean, rstd) of this layer's layer_norm1 when the previous layer's fc2 launch has produced it
+    layers = list(stack.layers)
+    for li, (layer, s) in enumerate(zip(layers, sh)):
+        if nxt_ln is not None:
+            h, m1, r1 = nxt_ln
+        else:
+            h, _, m1, r1 = ops.layernorm_fwd(x, layer.layer_norm1.weight, layer.layer_norm1.bias, a.eps, save_stats=save)
         qkv, _, _ = ops.gemm_nt(h, s["wqkv"], s["bqkv"])
         o, lse = ops.attention_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, H, S, S, D, scale, causal=causal,
                                    kbias=kbias, save_lse=save)
-        if lean:
-            x_mid, _, _ = ops.gemm_nt(o, s["wo"], layer.self_attn.out_proj.bias, resid=x)
+        if fuse:
+            x_mid, h2, m2, r2 = ops.gemm_nt_ln(o, s["wo"], layer.self_attn.out_proj.bias, x, layer.layer_norm2.weight,
+                                               layer.layer_norm2.bias, a.eps, save_stats=save)
         else:
-            _, x_mid, _ = ops.gemm_nt(o, s["wo"], layer.self_attn.out_proj.bias, resid=x, out_bf16=None, out_f32=True)
-        h2, _, m2, r2 = ops.layernorm_fwd(x_mid, layer.layer_norm2.weight, layer.layer_norm2.bias, a.eps,
-                                          save_stats=save)
+            if lean:
+                x_mid, _, _ = ops.gemm_nt(o, s["wo"], layer.self_attn.out_proj.bias, resid=x)
+            else:
+                _, x_mid, _ = ops.gemm_nt(o, s["wo"], layer.self_attn.out_proj.bias, resid=x, out_bf16=None, out_f32=True)
+            h2, _, m2, r2 = ops.layernorm_fwd(x_mid, layer.layer_norm2.weight, layer.layer_norm2.bias, a.eps,
+                                              save_stats=save)
         # (codes 5/6 — save quick_gelu'(z), multiply in the backward — exist in the C ABI; the pair measured 4 % slower
         #  end to end than saving z: the forward variant's sigmoid temporaries spill beside the 128 accumulators)
         act, _, z = ops.gemm_nt(h2, s["w1"], layer.mlp.fc1.bias, act=ops.ACT_QUICK_GELU, aux_out=True if save else None)
-        if lean:
+        nxt_ln = None
+        if fuse and li + 1 < len(layers):
+            nl = layers[li + 1].layer_norm1
+            x_out, hn, mn, rn = ops.gemm_nt_ln(act, s["w2"], layer.mlp.fc2.bias, x_mid, nl.weight, nl.bias, a.eps, save_stats=save)
+            nxt_ln = (hn, mn, rn)
+        elif lean:
             x_out, _, _ = ops.gemm_nt(act, s["w2"], layer.mlp.fc2.bias, resid=x_mid)
         else:
             _, x_out, _ = ops.gemm_nt(act, s["w2"], layer.mlp.fc2.bias, resid=x_mid, out_bf16=None, out_f32=True)

@@ -20,6 +20,8 @@ ACT_GELU_ERF, ACT_DGELU_ERF, ACT_ADD_AUX = 7, 8, 9
 _P, _I, _F, _Z, _L, _U64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_long, C.c_ulonglong
 _ARGTYPES = {
     "lc2is_gemm_nt_bf16": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
+    "lc2is_gemm_nt_ln_xchg_bytes": [_I, _I],
+    "lc2is_gemm_nt_ln_bf16": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _P, _F, _P, _I, _P, _P, _P, _Z, _I, _I, _I, _P],
     "lc2is_gemm_nt_bf16_batched": [_P, _I, _L, _P, _I, _L, _P, _I, _L, _P, _I, _L, _I, _I, _I, _I, _P],
     "lc2is_transpose_bf16_batched": [_P, _I, _L, _P, _I, _L, _I, _I, _I, _P],
     "lc2is_gemm_tn_workspace_bytes": [_I, _I, _I],
@@ -180,6 +182,49 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None, 
                                    _ld(ao), M, N, K, act, tile_cfg, _stream())
     _lib.check(rc, f"gemm_nt M={M} N={N} K={K}")
     return ob, of, ao
+
+
+_xchg_cache = {}
+# the GEMM + LayerNorm launch (round 5): LC2IS_LN_FUSE=0 keeps the two launches everywhere; rows from which the fused form is taken
+_LN_FUSE = os.environ.get("LC2IS_LN_FUSE", "1") != "0"
+_LN_FUSE_MIN_ROWS = int(os.environ.get("LC2IS_LN_FUSE_MIN_ROWS", "4096"))
+
+
+def gemm_nt_ln_ok(M: int, N: int, K: int) -> bool:
+    """Does gemm_nt_ln take this problem (else: gemm_nt + layernorm_fwd)?"""
+    return _LN_FUSE and N in (384, 768) and K % 64 == 0 and M >= max(256, _LN_FUSE_MIN_ROWS) and M % 256 <= 64
+
+
+def gemm_nt_ln(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None, resid: torch.Tensor | None, gamma: torch.Tensor,
+               beta: torch.Tensor | None, eps: float = 1e-5, *, save_stats: bool = True,
+               out_f32: torch.Tensor | None = None, ln_out: torch.Tensor | None = None):
+    """x = a @ w.T + bias (+ resid) in fp32 AND h = bf16(LayerNorm(x) * gamma + beta) in ONE launch (256x384 tiles, the two column
+    tiles of a row tile exchange row statistics).  a [M,K] bf16, w [N,K] bf16 with N in (384, 768), resid fp32 [M,N].
+    Returns (x_f32, h_bf16, mean, rstd) — what gemm_nt(..., out_f32=True) followed by layernorm_fwd returns."""
+    _chk(a, torch.bfloat16, "a"); _chk(w, torch.bfloat16, "w"); _chk(bias, torch.float32, "bias", 1)
+    _chk(resid, torch.float32, "resid"); _chk(gamma, torch.float32, "gamma", 1); _chk(beta, torch.float32, "beta", 1)
+    M, K = a.shape
+    N, K2 = w.shape
+    if K2 != K or gamma.numel() != N or (bias is not None and bias.numel() != N) or (beta is not None and beta.numel() != N):
+        raise RuntimeError("lc2is_amd.gemm_nt_ln: shape mismatch")
+    dev = a.device
+    xf = _out(out_f32 if out_f32 is not None else True, (M, N), torch.float32, dev)
+    h = _out(ln_out if ln_out is not None else True, (M, N), torch.bfloat16, dev)
+    mean = torch.empty((M,), dtype=torch.float32, device=dev) if save_stats else None
+    rstd = torch.empty((M,), dtype=torch.float32, device=dev) if save_stats else None
+    nb = _fn("lc2is_gemm_nt_ln_xchg_bytes")(M, N)
+    xc = None
+    if nb:
+        key = (str(dev), _stream())
+        xc = _xchg_cache.get(key)
+        if xc is None or xc.numel() < nb:
+            xc = torch.zeros(max(int(nb), 1 << 21), dtype=torch.uint8, device=dev)   # all zero once; every launch leaves it all zero
+            _xchg_cache[key] = xc
+    rc = _fn("lc2is_gemm_nt_ln_bf16")(_ptr(a), _ld(a), _ptr(w), _ld(w), _ptr(bias), _ptr(resid), _ld(resid), _ptr(xf), _ld(xf),
+                                      _ptr(gamma), _ptr(beta), float(eps), _ptr(h), _ld(h), _ptr(mean), _ptr(rstd), _ptr(xc),
+                                      xc.numel() if xc is not None else 0, M, N, K, _stream())
+    _lib.check(rc, f"gemm_nt_ln M={M} N={N} K={K}")
+    return xf, h, mean, rstd
 
 
 def gemm_nt_batched(a: torch.Tensor, w: torch.Tensor, *, out_bf16: torch.Tensor | bool | None = None,

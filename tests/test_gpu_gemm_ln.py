@@ -647,3 +647,52 @@ def test_cu_budget_changes_plans_not_results(dev):
         ops.set_cu_budget(0)
     with pytest.raises(Exception):
         ops.set_cu_budget(300)
+
+
+@pytest.mark.parametrize("M,N,K", [(32800, 768, 768), (32800, 768, 3072), (512, 768, 128), (300, 768, 192), (2048 + 64, 384, 256),
+                                   (1024, 768, 64)])
+@pytest.mark.parametrize("with_resid", [True, False])
+def test_gemm_nt_ln_fused_matches_the_two_launches(dev, M, N, K, with_resid):
+    """The GEMM + LayerNorm launch (256x384 tiles whose two column tiles exchange row statistics; round 5): the fp32 output is
+    BITWISE what gemm_nt writes, mean / rstd agree with the LayerNorm kernel to fp32 rounding (another summation order of the same
+    two-pass variance), the bf16 rows agree with it to one bf16 ulp, and against fp64 LayerNorm of that output they meet the
+    LayerNorm test's bound.  Run three times on the same exchange buffer (it must come back all zero), with the ragged
+    32 / 44 / 64 rows of B x 1025-token inputs and N = 384 (one column tile: no exchange)."""
+    from lc2is_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M * 13 + K)
+    a = _bf(torch.randn(M, K, generator=g)).to(dev)
+    w = _bf(torch.randn(N, K, generator=g) * 0.05).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    resid = (torch.randn(M, N, generator=g) * 3.0 + 0.7).to(dev) if with_resid else None
+    if resid is not None:
+        resid[:, 5] += 40.0          # an outlier channel, as CLIP's residual stream has
+    gamma = (torch.rand(N, generator=g) + 0.5).to(dev)
+    beta = torch.randn(N, generator=g).to(dev)
+    assert ops.gemm_nt_ln_ok(max(M, 4096), N, K)
+    _, x_ref, _ = ops.gemm_nt(a, w, bias, resid=resid, out_bf16=None, out_f32=True)
+    h_ref, _, m_ref, r_ref = ops.layernorm_fwd(x_ref, gamma, beta, 1e-5)
+    for rep in range(3):
+        x, h, mean, rstd = ops.gemm_nt_ln(a, w, bias, resid, gamma, beta, 1e-5)
+        torch.cuda.synchronize()
+        assert torch.equal(x, x_ref), rep
+        assert torch.isfinite(mean).all() and torch.isfinite(rstd).all()
+        assert (mean - m_ref).abs().max().item() <= 2e-6 * m_ref.abs().max().item() + 1e-6
+        assert ((rstd - r_ref).abs() / r_ref).max().item() < 5e-6
+        d = (h.float() - h_ref.float()).abs()
+        assert (d <= h_ref.float().abs() * 2.0 ** -7 + 1e-6).all(), rep                      # at most one bf16 ulp apart
+        assert (d > 0).float().mean().item() < 2e-2, rep                                     # ... and only where a rounding boundary sits
+        xd = x.double()
+        ln = (xd - xd.mean(1, keepdim=True)) / (xd.var(1, unbiased=False, keepdim=True) + 1e-5).sqrt() * gamma.double() + beta.double()
+        assert _rel(h.float(), ln) < 4e-3
+    for buf in ops._xchg_cache.values():
+        assert int(buf.view(torch.int64).ne(0).sum().item()) == 0   # every granule consumed and cleared
+
+
+def test_gemm_nt_ln_refuses_what_it_does_not_take(dev):
+    from lc2is_amd import ops
+    a = torch.zeros(400, 64, dtype=torch.bfloat16, device=dev)
+    gamma = torch.ones(768, device=dev)
+    with pytest.raises(RuntimeError):   # 144 ragged rows: more than the fragment jobs take
+        ops.gemm_nt_ln(a, torch.zeros(768, 64, dtype=torch.bfloat16, device=dev), None, None, gamma, None)
+    with pytest.raises(RuntimeError):   # N = 512
+        ops.gemm_nt_ln(a[:256], torch.zeros(512, 64, dtype=torch.bfloat16, device=dev), None, None, gamma[:512], None)
