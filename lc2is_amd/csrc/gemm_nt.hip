@@ -1229,7 +1229,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmNtArgs p, int ntile
   }
   // ---- folded ragged rows (see gemm_nt_w384_kernel): fragment jobs after the block's last tile (not in the derivative instantiation:
   // with its aux_in epilogue the section costs the 256-register kernel 12 bytes of scratch; dfc2 keeps its separate tail launch) ----
-  if constexpr (ACT != LC2IS_ACT_DQUICK_GELU)
+  if constexpr (ACT != LC2IS_ACT_DQUICK_GELU && ACT != LC2IS_ACT_DRELU)
   if (p.tail_rows > 0) {
     GemmNtArgs q = p;
     q.M = p.M + p.tail_rows;
@@ -1341,6 +1341,8 @@ int launch_pp(const GemmNtArgs& a, hipStream_t stream) {
     case LC2IS_ACT_DQUICK_GELU: return launch_pp_act<LC2IS_ACT_DQUICK_GELU>(a, stream);
     case LC2IS_ACT_NONE: return launch_pp_act<LC2IS_ACT_NONE>(a, stream);
     case LC2IS_ACT_ADD_AUX: return launch_pp_act<LC2IS_ACT_ADD_AUX>(a, stream);
+    case LC2IS_ACT_RELU: return launch_pp_act<LC2IS_ACT_RELU>(a, stream);     // (round 5: the decoders' linear1 / its dgrad at >= 2 rounds of tiles)
+    case LC2IS_ACT_DRELU: return launch_pp_act<LC2IS_ACT_DRELU>(a, stream);
     default: return LC2IS_ERR_UNSUPPORTED;
   }
 }
@@ -1460,7 +1462,8 @@ extern "C" int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw
   static const bool use_persist = !(getenv("LC2IS_GEMM_PERSIST") && atoi(getenv("LC2IS_GEMM_PERSIST")) == 0);
   static const long persist_min = getenv("LC2IS_GEMM_PERSIST_MIN") ? atol(getenv("LC2IS_GEMM_PERSIST_MIN")) : 257;   // more than one round of tiles (A/B 512 -> 257: 907 -> 915 img/s)
   if (use_persist && persist2_ok(a) && (long)((M + 255) / 256) * (N / 256) >= persist_min &&
-      (act == LC2IS_ACT_NONE || act == LC2IS_ACT_QUICK_GELU || act == LC2IS_ACT_DQUICK_GELU || act == LC2IS_ACT_ADD_AUX)) {
+      (act == LC2IS_ACT_NONE || act == LC2IS_ACT_QUICK_GELU || act == LC2IS_ACT_DQUICK_GELU || act == LC2IS_ACT_ADD_AUX ||
+       act == LC2IS_ACT_RELU || act == LC2IS_ACT_DRELU)) {
     // One block per CU walks tiles t, t + 256, ...: the launch lasts ceil(tiles / 256) tile times.  The ragged last <= 64 rows
     // (B x 1025 tokens: 32 rows, i.e. one more row of N / 256 tiles) are peeled off into a small-tile launch when that saves a
     // whole tile time: fc1 / dfc2 at M = 32 800 walk 1548 tiles = 6 rounds + 12 tiles, 1536 = exactly 6 without the 32 rows.
@@ -1471,7 +1474,7 @@ extern "C" int lc2is_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw
     if (peel && r > 0 && r <= 64 && M > 256 && lc2is_rounds(tiles_main) < lc2is_rounds(tiles_all)) {
       GemmNtArgs main_part = a, tail = a;
       main_part.M = M - r;
-      if (fold_tail && pcfg == 15 && N % 16 == 0 && act != LC2IS_ACT_DQUICK_GELU) main_part.tail_rows = r;
+      if (fold_tail && pcfg == 15 && N % 16 == 0 && act != LC2IS_ACT_DQUICK_GELU && act != LC2IS_ACT_DRELU) main_part.tail_rows = r;
       int rc = launch_by_cfg(main_part, pcfg, stream);
       if (rc || main_part.tail_rows) return rc;
       const size_t m0 = (size_t)(M - r);

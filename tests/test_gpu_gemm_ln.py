@@ -131,6 +131,12 @@ def test_gemm_nt_ping_pong_is_bitwise_equal(dev, M, N, K):
         d4, _, _ = ops.gemm_nt(a, w, None, act=ops.ACT_DQUICK_GELU, aux_in=saved, tile_cfg=4)
         d15, _, _ = ops.gemm_nt(a, w, None, act=ops.ACT_DQUICK_GELU, aux_in=saved, tile_cfg=15)
         assert torch.equal(d4, d15)
+        r4, _, _ = ops.gemm_nt(a, w, bias, act=ops.ACT_RELU, tile_cfg=4)          # (round 5: the decoders' linear1 and its dgrad)
+        r15, _, _ = ops.gemm_nt(a, w, bias, act=ops.ACT_RELU, tile_cfg=15)
+        assert torch.equal(r4, r15)
+        d4, _, _ = ops.gemm_nt(a, w, None, act=ops.ACT_DRELU, aux_in=saved, tile_cfg=4)
+        d15, _, _ = ops.gemm_nt(a, w, None, act=ops.ACT_DRELU, aux_in=saved, tile_cfg=15)
+        assert torch.equal(d4, d15)
     ref = a.double() @ w.double().T + bias.double()
     assert _rel(ops.gemm_nt(a, w, bias, tile_cfg=15)[0].float(), ref) < 4e-3
 
