@@ -64,7 +64,7 @@ __device__ __forceinline__ void gemm_epilogue_act(const GemmNtArgs& p, f32x4_t (
         f32x4_t d;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float sg = sigmoidf_fast(1.702f * v[r]);
+          const float sg = quick_sigmoid(v[r]);
           d[r] = sg * (1.f + 1.702f * v[r] * (1.f - sg));
           v[r] *= sg;
         }
@@ -80,7 +80,7 @@ __device__ __forceinline__ void gemm_epilogue_act(const GemmNtArgs& p, f32x4_t (
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           v[r] = (act == LC2IS_ACT_RELU) ? fmaxf(v[r], 0.f)
-                                         : (act == LC2IS_ACT_GELU_ERF ? gelu_erf(v[r]) : v[r] * sigmoidf_fast(1.702f * v[r]));
+                                         : (act == LC2IS_ACT_GELU_ERF ? gelu_erf(v[r]) : v[r] * quick_sigmoid(v[r]));
       } else if (kAux) {
         const i32x2_t zk = zv[jj];
         float z[4] = {bf16_to_f32((bf16_t)(zk[0] & 0xffff)), bf16_to_f32((bf16_t)((unsigned)zk[0] >> 16)),
@@ -96,7 +96,7 @@ __device__ __forceinline__ void gemm_epilogue_act(const GemmNtArgs& p, f32x4_t (
           } else if (act == LC2IS_ACT_DGELU_ERF) {
             v[r] *= dgelu_erf(z[r]);
           } else {
-            const float s = sigmoidf_fast(1.702f * z[r]);
+            const float s = quick_sigmoid(z[r]);
             v[r] *= s * (1.f + 1.702f * z[r] * (1.f - s));
           }
         }
@@ -204,7 +204,7 @@ __device__ __forceinline__ void gemm_epilogue_lds_act(const GemmNtArgs& p, f32x4
           f32x4_t d;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float sg = sigmoidf_fast(1.702f * v[r]);
+            const float sg = quick_sigmoid(v[r]);
             d[r] = sg * (1.f + 1.702f * v[r] * (1.f - sg));
             v[r] *= sg;
           }
@@ -226,7 +226,7 @@ __device__ __forceinline__ void gemm_epilogue_lds_act(const GemmNtArgs& p, f32x4
             } else if (act == LC2IS_ACT_DRELU) {
               v[r] = z[r] > 0.f ? v[r] : 0.f;
             } else {
-              const float sg = sigmoidf_fast(1.702f * z[r]);
+              const float sg = quick_sigmoid(z[r]);
               v[r] *= sg * (1.f + 1.702f * z[r] * (1.f - sg));
             }
           }
@@ -284,7 +284,7 @@ __device__ __forceinline__ void gemm_epilogue_lds_act(const GemmNtArgs& p, f32x4
           f32x4_t v = acc[i][jg * 4 + jl];
           if (act == LC2IS_ACT_QUICK_GELU) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = v[r] * sigmoidf_fast(1.702f * v[r]);
+            for (int r = 0; r < 4; ++r) v[r] = v[r] * quick_sigmoid(v[r]);
           } else if (act == LC2IS_ACT_GELU_ERF) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);

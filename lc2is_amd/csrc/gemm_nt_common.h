@@ -32,6 +32,10 @@ struct GemmNtArgs {
 };
 
 __device__ __forceinline__ float sigmoidf_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }  // v_exp + v_rcp
+// sigmoid(1.702 x) of quick_gelu (hf:activations.py QuickGELUActivation) with the two constants of exp(-1.702 x) = exp2(-1.702 log2(e) x)
+// folded into ONE multiply (round 5: sigmoidf_fast(1.702f * x) cost two — hipcc may not reassociate float products — in an epilogue
+// whose cost IS its vector arithmetic: 44 -> 40 issue cycles per element beside the 128 accumulators of a lane)
+__device__ __forceinline__ float quick_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -2.4554669596f)); }
 // exact GELU of hf:activations.py "gelu" (Swin MLP, modeling_swin.py:474): 0.5 x (1 + erf(x / sqrt 2)) and its derivative
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 // derivative = Phi(x) + x phi(x).  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 gradient it scales):
