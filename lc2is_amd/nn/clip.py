@@ -175,8 +175,8 @@ def _stack_fwd(x, stack: _Stack, sh, a: ClipArch, B: int, S: int, kbias, causal:
     saved = []
     lean = x.dtype == torch.bfloat16
     # round 5: on an fp32 stream the two residual-join GEMMs of a layer also write the LayerNorm that follows them (layer_norm2
-    # behind out-proj, the NEXT layer's layer_norm1 behind fc2) — ops.gemm_nt_ln, one launch instead of two (N = 768 / 384 towers
-    # at >= 4096 rows: the ViT-B vision tower; every other stack keeps the LayerNorm kernel)
+    # behind out-proj, the NEXT layer's layer_norm1 behind fc2) — ops.gemm_nt_ln, one launch instead of two (width 768 / 384 at
+    # enough rows for the 256x384 tiles to fill the chip: the ViT-B vision tower at B >= 28; every other stack keeps the LayerNorm kernel)
     fuse = (not lean) and ops.gemm_nt_ln_ok(x.shape[0], C, C) and ops.gemm_nt_ln_ok(x.shape[0], C, a.intermediate)
     nxt_ln = None   # (h, mean, rstd) of this layer's layer_norm1 when the previous layer's fc2 launch has produced it
     layers = list(stack.layers)

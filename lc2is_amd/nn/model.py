@@ -223,7 +223,7 @@ class BaseModelWithText(HipModule):
         else:
             enc_t = self.text_encoder(**text_inputs)                                          # model.py:32
             enc_v = self.vision_encoder(**vision_inputs)                                      # model.py:35
-        kpm = torch.where(text_inputs["attention_mask"] == 1, False, True)                    # model.py:38
+        kpm = text_inputs["attention_mask"] != 1    # model.py:38 `torch.where(mask == 1, False, True)`: the same bool tensor in one launch instead of four
         return self.vision_decoder(tgt=enc_v, memory=enc_t, memory_key_padding_mask=kpm)
 
     def forward(self, inputs: dict) -> dict:

@@ -187,12 +187,18 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None, 
 _xchg_cache = {}
 # the GEMM + LayerNorm launch (round 5): LC2IS_LN_FUSE=0 keeps the two launches everywhere; rows from which the fused form is taken
 _LN_FUSE = os.environ.get("LC2IS_LN_FUSE", "1") != "0"
-_LN_FUSE_MIN_ROWS = int(os.environ.get("LC2IS_LN_FUSE_MIN_ROWS", "4096"))
+# 0 = where the 256x384 tiles fill the chip anyway: 224 tiles (7/8 of a round of the 256 CUs, the large-tile rule of lc2is_gemm_nt_bf16) —
+# M >= 28 672 at N = 768; below that the unfused plan's smaller tiles keep more CUs busy than 2 x M / 256 blocks would
+_LN_FUSE_MIN_ROWS = int(os.environ.get("LC2IS_LN_FUSE_MIN_ROWS", "0"))
 
 
 def gemm_nt_ln_ok(M: int, N: int, K: int) -> bool:
-    """Does gemm_nt_ln take this problem (else: gemm_nt + layernorm_fwd)?"""
-    return _LN_FUSE and N in (384, 768) and K % 64 == 0 and M >= max(256, _LN_FUSE_MIN_ROWS) and M % 256 <= 64
+    """Should this problem take gemm_nt_ln (else: gemm_nt + layernorm_fwd)?"""
+    if not (_LN_FUSE and N in (384, 768) and K % 64 == 0 and M >= 256 and M % 256 <= 64):
+        return False
+    if _LN_FUSE_MIN_ROWS > 0:
+        return M >= _LN_FUSE_MIN_ROWS
+    return (M // 256) * (N // 384) >= 224
 
 
 def gemm_nt_ln(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None, resid: torch.Tensor | None, gamma: torch.Tensor,
