@@ -875,10 +875,7 @@ __global__ __launch_bounds__(512) void gemm_nt_w384_kernel(GemmNtArgs p) {
           // (row step in the VECTOR offset: with a register in the scalar-offset field hipcc inserts no wait state between a 16-byte
           //  buffer store and a VALU write of its data registers — LLVM models that case as hazard-free — and on gfx950 the first
           //  dword of some lanes was stored as the zero a following v_mov_b32 put there: found with this epilogue, round 5)
-#ifndef LC2IS_LN_X_POLICY
-#define LC2IS_LN_X_POLICY 0
-#endif
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, v), rsO, o_off[q % 3] + rb * o_step, 0, LC2IS_LN_X_POLICY);   // write-back policy
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, v), rsO, o_off[q % 3] + rb * o_step, 0, 0);   // write-back (non-temporal measured equal in the step: 1076 vs 1077 img/s)
         }
       }
 #pragma unroll
@@ -928,11 +925,7 @@ __global__ __launch_bounds__(512) void gemm_nt_w384_kernel(GemmNtArgs p) {
       const float my_m2 = (q4[0] + q4[1]) + (q4[2] + q4[3]);
       float cm = my_mean, cq = my_m2;
       if (gr < p.M) {
-#ifdef LC2IS_LN_DBG_NOXCHG
-        if (false) {
-#else
-        if (ntn == 2) {
-#endif
+        if (ntn == 2) {   // (a diagnostic build without the exchange: 75.3 against 77.1 us for out-proj — it costs 1.8 us)
           constexpr unsigned long long TAG = 0x4C4E0001ull << 32;
           unsigned long long* mine = p.ln_xchg + ((size_t)gr * 2 + tn) * 2;
           unsigned long long* theirs = p.ln_xchg + ((size_t)gr * 2 + (tn ^ 1)) * 2;
