@@ -37,7 +37,7 @@ def test_shadow_refresh_and_casts(dev):
     assert torch.equal(ops.transpose_bf16(xb), xb.T.contiguous())
 
 
-@pytest.mark.parametrize("B,H,ps,C", [(2, 64, 16, 192), (1, 128, 16, 768), (2, 70, 14, 64)])
+@pytest.mark.parametrize("B,H,ps,C", [(2, 64, 16, 192), (1, 128, 16, 768), (2, 70, 14, 64), (1, 72, 16, 64), (3, 512, 16, 64)])
 def test_patch_embedding_path(dev, B, H, ps, C):
     from lc2is_amd import ops
     g = torch.Generator(device="cpu").manual_seed(1)
