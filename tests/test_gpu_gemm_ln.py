@@ -702,3 +702,38 @@ def test_gemm_nt_ln_refuses_what_it_does_not_take(dev):
         ops.gemm_nt_ln(a, torch.zeros(768, 64, dtype=torch.bfloat16, device=dev), None, None, gamma, None)
     with pytest.raises(RuntimeError):   # N = 512
         ops.gemm_nt_ln(a[:256], torch.zeros(512, 64, dtype=torch.bfloat16, device=dev), None, None, gamma[:512], None)
+
+
+def test_vision_tower_with_fused_layernorm_launches_matches_the_separate_ones(dev, monkeypatch):
+    """The ViT tower's forward AND backward with out-proj / fc2 writing the LayerNorm that follows them (ops.gemm_nt_ln), against the same
+    tower with the LayerNorm kernel: the modules take the fused launch only from 224 tiles on (B >= 28 at 512 x 512), so the row
+    threshold is lowered here — 3 layers, B = 2 (M = 2050: 8 row tiles + 2 ragged rows).  The statistics differ in the last fp32 bits
+    and a bf16 row element by at most one ulp; tokens and gradients agree far inside the bf16 noise of either form."""
+    import lc2is_amd.nn as N
+    from lc2is_amd import ops
+    torch.manual_seed(7)
+    base = N.ImageEncoderCLIP(512, 16, arch=N.ClipArch(768, 12, 3, 3072))
+    sd = {k: v.detach().clone() for k, v in base.state_dict().items()}
+    pix = torch.randn(2, 3, 512, 512, generator=torch.Generator().manual_seed(3)).to(dev)
+    gout = None
+    res = {}
+    for fused in (False, True):
+        monkeypatch.setattr(ops, "_LN_FUSE", fused)
+        monkeypatch.setattr(ops, "_LN_FUSE_MIN_ROWS", 256)
+        assert ops.gemm_nt_ln_ok(2050, 768, 768) == fused
+        enc = N.ImageEncoderCLIP(512, 16, arch=N.ClipArch(768, 12, 3, 3072))   # (a fresh module: gradient buffers accumulate)
+        enc.load_state_dict(sd)
+        enc = enc.to(dev).train()
+        out = enc(pixel_values=pix)
+        out = out if torch.is_tensor(out) else out[0]
+        if gout is None:
+            gout = torch.randn(out.shape, generator=torch.Generator().manual_seed(4)).to(dev)
+        out.backward(gout)
+        res[fused] = (out.detach().clone(), {k: v.grad.detach().clone() for k, v in enc.named_parameters() if v.grad is not None})
+    o0, g0 = res[False]
+    o1, g1 = res[True]
+    assert _rel(o1, o0) < 1e-3, _rel(o1, o0)
+    # (k_proj.bias: its true gradient is zero — softmax ignores a per-query constant — so both forms hold rounding noise only)
+    rels = {k: _rel(g1[k], g0[k]) for k in g0 if not k.endswith("k_proj.bias")}
+    worst = max(rels.values())
+    assert set(g0) == set(g1) and worst < 1e-2, sorted(rels.items(), key=lambda kv: -kv[1])[:6]   # measured 4.8e-3 (layer_norm1.weight of layer 0)
